@@ -1,0 +1,129 @@
+/*
+ * mi_features.h -- C ABI of libmi_features.so: GPU-resident SIFT / SURF feature
+ * extraction and brute-force descriptor matching for AMD MI355X (gfx950).
+ *
+ * This is the boundary a maintainer of the reference binds instead of the
+ * coopcl OpenCL driver. Each entry point names the reference interface it
+ * replaces. All functions return 0 on success and a negative MIF_ERR_* code on
+ * failure; they never call exit(). mif_last_error() returns a description of
+ * the last failure on the calling thread.
+ *
+ * Pointers whose name starts with d_ are device (HBM) addresses on the handle's
+ * GPU; all others are host addresses. No type of this header depends on HIP or
+ * torch.
+ */
+#ifndef MI_FEATURES_H
+#define MI_FEATURES_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIF_OK 0
+/* An octave produced no keypoint; SIFT::extract_features returns -1 in that
+ * case (reference SIFT/sift.cpp:1257-1258, 1870-1876). */
+#define MIF_ERR_NO_KEYPOINTS (-1)
+#define MIF_ERR_INVALID_ARGUMENT (-2)
+#define MIF_ERR_HIP (-3)
+#define MIF_ERR_CAPACITY (-4)
+#define MIF_ERR_UNSUPPORTED (-5)
+
+#define MIF_SIFT_OCTAVES 3   /* _SIFT_MAX_OCTAVES, SIFT/sift.cpp:24 */
+#define MIF_SIFT_LEVELS 6    /* _SIFT_INTVLS + 3,  SIFT/sift.cpp:17,23 */
+#define MIF_SIFT_DESC_DIM 128
+
+const char* mif_last_error(void);
+int mif_device_count(void);
+
+/* ------------------------------------------------------------------ SIFT -- */
+
+typedef struct mif_sift mif_sift;
+
+/* Replaces SIFT::init / sift_algorithm::sift_algorithm / sift_octave ctor
+ * (SIFT/sift.cpp:2148-2189, 1731-1770, 1291-1538): builds the per-octave buffer
+ * plan for a width x height image with `channels` = 1 (gray) or 3 (interleaved
+ * BGR) on GPU `device`. up_scale must be 0. */
+int mif_sift_create(int device, int width, int height, int channels, int up_scale, mif_sift** out);
+int mif_sift_destroy(mif_sift* s);
+
+/* Geometry of octave o: size_t(w / 2^o), size_t(h / 2^o), max_features =
+ * items / 100 (SIFT/sift.cpp:1313-1314, 1356). Any out pointer may be NULL. */
+int mif_sift_octave_info(const mif_sift* s, int octave, int* width, int* height, int* max_features);
+/* Sum of max_features over the octaves: the row capacity of every result buffer. */
+int mif_sift_capacity(const mif_sift* s);
+
+/* Replaces both SIFT::extract_features overloads (SIFT/sift.h:51-69,
+ * SIFT/sift.cpp:2191-2217) for host buffers.
+ *   pixels        width*height*channels bytes
+ *   keypoints     capacity x 4 floats {x, y, sigma, level}   (float4 of sift.cpp:410-413)
+ *   orientations  capacity floats, or NULL (detector only)
+ *   descriptors   capacity x 128 floats, or NULL
+ *   counts        keypoints per octave; rows are octave-major (sift.cpp:1889-1911)
+ *                 and inside an octave ordered by (level, y, x) of the detecting pixel
+ *   elapsed_ms    GPU time from first to last kernel of the frame, or NULL
+ * Returns MIF_ERR_NO_KEYPOINTS (and all counts 0) if descriptors were requested
+ * and some octave found nothing. */
+int mif_sift_extract(mif_sift* s, const uint8_t* pixels, float* keypoints, float* orientations,
+                     float* descriptors, int capacity, int counts[MIF_SIFT_OCTAVES], float* elapsed_ms);
+
+/* Device-resident form of the same call: d_pixels already lives in HBM, the
+ * frame is enqueued on the handle's stream and nothing is copied back.
+ * want_descriptors = 0 stops after the detector (first overload of sift.h). */
+int mif_sift_enqueue(mif_sift* s, const void* d_pixels, int want_descriptors);
+/* Blocks until everything enqueued on the handle has finished. */
+int mif_sift_sync(mif_sift* s);
+/* Device addresses of the last frame's results, valid until the next enqueue:
+ * keypoints float4[capacity], orientations float[capacity], descriptors
+ * float[capacity][128], counts int32[8] = {n_oct0, n_oct1, n_oct2, n_total,
+ * raw_oct0, raw_oct1, raw_oct2, status}. Any out pointer may be NULL. */
+int mif_sift_device_results(mif_sift* s, void** d_keypoints, void** d_orientations, void** d_descriptors,
+                            void** d_counts);
+/* The handle's hipStream_t, for callers that order their own work after a frame. */
+void* mif_sift_stream(mif_sift* s);
+/* Waits for the stream and reads the per-octave counts (clamped to
+ * max_features) and raw detector totals. Either array may be NULL. */
+int mif_sift_read_counts(mif_sift* s, int counts[MIF_SIFT_OCTAVES], int raw_counts[MIF_SIFT_OCTAVES]);
+
+/* Replace the _DEBUG probes SIFT::get_blur / get_diff_blur (SIFT/sift.h:13-21):
+ * copy one image of the last frame's scale space to the host.
+ * level 0..5 of the Gaussian pyramid, index 0..4 of the DoG stack. */
+int mif_sift_copy_level(mif_sift* s, int octave, int level, float* out);
+int mif_sift_copy_dog(mif_sift* s, int octave, int index, float* out);
+/* Gaussian taps of a level as the blur kernels use them (2*radius+1 floats;
+ * Build_separable_filter_cof, SIFT/sift.cpp:819-889). Returns the radius. */
+int mif_sift_taps(const mif_sift* s, int level, float* out, int capacity);
+/* GPU time of the last synchronised frame in ms (hipEvent pair). */
+int mif_sift_last_elapsed_ms(mif_sift* s, float* ms);
+
+/* -------------------------------------------------------------- matching -- */
+
+typedef struct mif_matcher mif_matcher;
+
+/* Workspace for matching up to max_query x max_database descriptors on `device`. */
+int mif_match_create(int device, int max_query, int max_database, mif_matcher** out);
+int mif_match_destroy(mif_matcher* m);
+
+/* Exact brute-force 2-nearest-neighbour search in L2; replaces the
+ * cv::FlannBasedMatcher::match / knnMatch(k=2) calls of common/kpmatch.h:174-176
+ * and 284-286. Row i of q / db starts at q + i*ld; only the first `dim` floats of
+ * a row take part (dim = 127, ld = 128 reproduces the shifted descriptor row of
+ * kpmatch.h:15,127-128,141-142). For every query row the two database rows with
+ * the smallest distance are returned, nearest first, ties to the lowest index:
+ * idx2[2*i], idx2[2*i+1] (-1 when the database has fewer rows) and the Euclidean
+ * distances dist2[2*i], dist2[2*i+1] (+inf when missing). */
+int mif_match_top2(mif_matcher* m, const float* q, int nq, const float* db, int nd, int dim, int ld,
+                   int32_t* idx2, float* dist2);
+/* Device-resident form, enqueued on `stream` (a hipStream_t, NULL = default).
+ * d_nq / d_nd, when not NULL, point to device int32 row counts that override
+ * nq / nd (which then are the capacities the grid is sized for). */
+int mif_match_top2_device(mif_matcher* m, const float* d_q, int nq, const int32_t* d_nq, const float* d_db,
+                          int nd, const int32_t* d_nd, int dim, int ld, int32_t* d_idx2, float* d_dist2,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_FEATURES_H */

@@ -1,0 +1,75 @@
+"""ctypes binding of the C ABI declared in include/mi_features.h."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MIF_OK = 0
+MIF_ERR_NO_KEYPOINTS = -1
+MIF_ERR_INVALID_ARGUMENT = -2
+MIF_ERR_HIP = -3
+MIF_ERR_CAPACITY = -4
+MIF_ERR_UNSUPPORTED = -5
+
+# every symbol include/mi_features.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+_PI = C.POINTER(C.c_int)
+_PF = C.POINTER(C.c_float)
+SYMBOLS = [
+    ("mif_last_error", C.c_char_p, []),
+    ("mif_device_count", C.c_int, []),
+    ("mif_sift_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("mif_sift_destroy", C.c_int, [_P]),
+    ("mif_sift_octave_info", C.c_int, [_P, C.c_int, _PI, _PI, _PI]),
+    ("mif_sift_capacity", C.c_int, [_P]),
+    ("mif_sift_extract", C.c_int, [_P, _P, _P, _P, _P, C.c_int, _PI, _PF]),
+    ("mif_sift_enqueue", C.c_int, [_P, _P, C.c_int]),
+    ("mif_sift_sync", C.c_int, [_P]),
+    ("mif_sift_device_results", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    ("mif_sift_stream", _P, [_P]),
+    ("mif_sift_read_counts", C.c_int, [_P, _PI, _PI]),
+    ("mif_sift_copy_level", C.c_int, [_P, C.c_int, C.c_int, _P]),
+    ("mif_sift_copy_dog", C.c_int, [_P, C.c_int, C.c_int, _P]),
+    ("mif_sift_taps", C.c_int, [_P, C.c_int, _PF, C.c_int]),
+    ("mif_sift_last_elapsed_ms", C.c_int, [_P, _PF]),
+    ("mif_match_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("mif_match_destroy", C.c_int, [_P]),
+    ("mif_match_top2", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    ("mif_match_top2_device", C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P]),
+]
+
+
+class MifError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libmi_features error %d: %s" % (code, message))
+        self.code = code
+
+
+def library_path():
+    return os.path.join(_HERE, "libmi_features.so")
+
+
+def load_library():
+    """Loads libmi_features.so; raises if it has not been built (no fallback path exists)."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                "%s is missing: build it with `make -C object_detection_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback" % path)
+        lib = C.CDLL(path)
+        for name, restype, argtypes in SYMBOLS:
+            fn = getattr(lib, name)          # AttributeError if the ABI lacks a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _LIB = lib
+    return _LIB
+
+
+def check(code, allow=()):
+    if code != MIF_OK and code not in allow:
+        msg = load_library().mif_last_error()
+        raise MifError(code, msg.decode("utf-8", "replace") if msg else "")
+    return code

@@ -1,0 +1,364 @@
+// Brute-force L2 two-nearest-neighbour descriptor matching on the MI355X matrix
+// cores. Replaces the cv::FlannBasedMatcher::match / knnMatch(k=2) calls of the
+// reference (common/kpmatch.h:174-176, 284-286) with an exact search.
+//
+// Definition (fixed so that every run and every machine returns the same bits):
+//   nq_i  = sum_k q_ik^2, nd_j = sum_k d_jk^2        fmaf chains, k ascending from 0
+//   dot_ij = sum_k q_ik d_jk                          fmaf chain, k ascending from 0
+//   s_ij  = fmaf(-2, dot_ij, nq_i + nd_j)             ranking score (squared L2)
+//   the two smallest (s_ij, j) in lexicographic order win (ties -> lowest index)
+//   reported distance = sqrt(sum_k (q_ik - d_jk)^2)   fmaf chain, k ascending,
+//   and the two winners are swapped if that puts the smaller distance first.
+// v_mfma_f32_32x32x2_f32 accumulates exactly such a k-ordered fmaf chain, so the
+// GEMM below reproduces dot_ij bit for bit.
+#include <algorithm>
+#include <cstdint>
+#include <cmath>
+#include "mif_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kQT = 32;      // query rows per wave (one 32x32 MFMA tile)
+constexpr int kWaves = 4;    // waves per block, each with its own query tile
+constexpr int kDC = 32;      // database rows per staged chunk
+constexpr float kInf = __builtin_inff();
+
+__global__ void k_row_norms(const float* __restrict__ m, int n_cap, const int* __restrict__ d_n, int dim, int ld,
+                            float* __restrict__ out)
+{
+    const int n = d_n ? min(*d_n, n_cap) : n_cap;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = m + (size_t)i * ld;
+    float acc = 0.0f;
+    for (int k = 0; k < dim; k++) acc = __builtin_fmaf(r[k], r[k], acc);
+    out[i] = acc;
+}
+
+struct Top2 {
+    float s1, s2;
+    int i1, i2;
+};
+
+__device__ __forceinline__ bool before(float sa, int ia, float sb, int ib)
+{
+    return sa < sb || (sa == sb && ia < ib);
+}
+
+// merge candidate (s, i) into a sorted pair
+__device__ __forceinline__ void top2_insert(Top2& t, float s, int i)
+{
+    if (before(s, i, t.s1, t.i1)) {
+        t.s2 = t.s1; t.i2 = t.i1;
+        t.s1 = s; t.i1 = i;
+    } else if (before(s, i, t.s2, t.i2)) {
+        t.s2 = s; t.i2 = i;
+    }
+}
+
+// grid: (ceil(nq_cap / 128), nsplit). Wave v of block b owns query rows
+// [128 b + 32 v, +32); the block walks its share of the database in chunks of
+// 32 rows staged in LDS and shared by the four waves.
+template <int KSTEPS>
+__global__ __launch_bounds__(256) void k_match_partial(const float* __restrict__ Q, int nq_cap,
+                                                       const int* __restrict__ d_nq, const float* __restrict__ D,
+                                                       int nd_cap, const int* __restrict__ d_nd, int dim, int ld,
+                                                       const float* __restrict__ qn, const float* __restrict__ dn,
+                                                       int nsplit, float* __restrict__ part_s,
+                                                       int* __restrict__ part_i)
+{
+    constexpr int KP = 2 * KSTEPS + 1;     // odd pitch: conflict-free column reads
+    __shared__ float s_b[kDC * KP];
+    const int nq = d_nq ? min(*d_nq, nq_cap) : nq_cap;
+    const int nd = d_nd ? min(*d_nd, nd_cap) : nd_cap;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const int qbase = blockIdx.x * (kQT * kWaves) + wave * kQT;
+    if (blockIdx.x * (kQT * kWaves) >= nq) return;          // uniform over the block
+
+    // A fragments: lane holds q[qbase + col][2 kk + half]
+    float qf[KSTEPS];
+    {
+        const int qi = qbase + col;
+        const float* qr = Q + (size_t)min(qi, nq_cap - 1) * ld;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; kk++) {
+            const int k = 2 * kk + half;
+            qf[kk] = (qi < nq && k < dim) ? qr[k] : 0.0f;
+        }
+    }
+    // rows of the 32x32 result held by this lane: (reg&3) + 8 (reg>>2) + 4 half
+    float qnr[16];
+    Top2 best[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int row = qbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+        qnr[r] = (row < nq) ? qn[row] : 0.0f;
+        best[r].s1 = best[r].s2 = kInf;
+        best[r].i1 = best[r].i2 = 0x7fffffff;
+    }
+
+    const int chunks = (nd + kDC - 1) / kDC;
+    const int per = (chunks + nsplit - 1) / nsplit;
+    const int c_lo = blockIdx.y * per;
+    const int c_hi = min(chunks, c_lo + per);
+    for (int c = c_lo; c < c_hi; c++) {
+        __syncthreads();
+        for (int idx = tid; idx < kDC * 2 * KSTEPS; idx += 256) {
+            const int r = idx / (2 * KSTEPS);
+            const int k = idx - r * (2 * KSTEPS);
+            const int j = c * kDC + r;
+            s_b[r * KP + k] = (j < nd && k < dim) ? D[(size_t)j * ld + k] : 0.0f;
+        }
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; kk++) {
+            const float b = s_b[col * KP + 2 * kk + half];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[kk], b, acc, 0, 0, 0);
+        }
+        const int j = c * kDC + col;
+        if (j < nd) {
+            const float dnj = dn[j];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float s = __builtin_fmaf(-2.0f, acc[r], qnr[r] + dnj);
+                // j grows monotonically per lane, so strict '<' keeps the lowest index on ties
+                if (s < best[r].s1) {
+                    best[r].s2 = best[r].s1; best[r].i2 = best[r].i1;
+                    best[r].s1 = s; best[r].i1 = j;
+                } else if (s < best[r].s2) {
+                    best[r].s2 = s; best[r].i2 = j;
+                }
+            }
+        }
+    }
+    // merge the 32 lanes (database columns) of each half
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        Top2 t = best[r];
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            const float os1 = __shfl_xor(t.s1, off), os2 = __shfl_xor(t.s2, off);
+            const int oi1 = __shfl_xor(t.i1, off), oi2 = __shfl_xor(t.i2, off);
+            top2_insert(t, os1, oi1);
+            top2_insert(t, os2, oi2);
+        }
+        const int row = qbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (col == 0 && row < nq) {
+            const size_t o = ((size_t)blockIdx.y * nq_cap + row) * 2;
+            part_s[o] = t.s1; part_s[o + 1] = t.s2;
+            part_i[o] = t.i1; part_i[o + 1] = t.i2;
+        }
+    }
+}
+
+__device__ __forceinline__ float exact_dist(const float* __restrict__ q, const float* __restrict__ d, int dim)
+{
+    float acc = 0.0f;
+    for (int k = 0; k < dim; k++) {
+        const float df = q[k] - d[k];
+        acc = __builtin_fmaf(df, df, acc);
+    }
+    return __builtin_sqrtf(acc);
+}
+
+__global__ void k_match_finalize(const float* __restrict__ Q, int nq_cap, const int* __restrict__ d_nq,
+                                 const float* __restrict__ D, int nd_cap, const int* __restrict__ d_nd, int dim,
+                                 int ld, int nsplit, const float* __restrict__ part_s,
+                                 const int* __restrict__ part_i, int* __restrict__ idx2, float* __restrict__ dist2)
+{
+    const int nq = d_nq ? min(*d_nq, nq_cap) : nq_cap;
+    const int nd = d_nd ? min(*d_nd, nd_cap) : nd_cap;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    Top2 t;
+    t.s1 = t.s2 = kInf;
+    t.i1 = t.i2 = 0x7fffffff;
+    const int chunks = (nd + kDC - 1) / kDC;
+    const int per = (chunks + nsplit - 1) / nsplit;
+    for (int sp = 0; sp < nsplit; sp++) {
+        if (sp * per >= chunks) break;                  // this split had no database rows
+        const size_t o = ((size_t)sp * nq_cap + i) * 2;
+        top2_insert(t, part_s[o], part_i[o]);
+        top2_insert(t, part_s[o + 1], part_i[o + 1]);
+    }
+    int j1 = (t.i1 < nd) ? t.i1 : -1;
+    int j2 = (t.i2 < nd) ? t.i2 : -1;
+    const float* q = Q + (size_t)i * ld;
+    float e1 = (j1 >= 0) ? exact_dist(q, D + (size_t)j1 * ld, dim) : kInf;
+    float e2 = (j2 >= 0) ? exact_dist(q, D + (size_t)j2 * ld, dim) : kInf;
+    if (j2 >= 0 && (e2 < e1 || (e2 == e1 && j2 < j1))) {
+        const float te = e1; e1 = e2; e2 = te;
+        const int tj = j1; j1 = j2; j2 = tj;
+    }
+    idx2[2 * i] = j1; idx2[2 * i + 1] = j2;
+    dist2[2 * i] = e1; dist2[2 * i + 1] = e2;
+}
+
+} // namespace
+
+struct mif_matcher {
+    int device = 0, max_q = 0, max_d = 0, max_split = 1;
+    float* qn = nullptr;
+    float* dn = nullptr;
+    float* part_s = nullptr;
+    int* part_i = nullptr;
+    // staging for the host-buffer entry point
+    float* d_q = nullptr;
+    float* d_db = nullptr;
+    size_t d_q_bytes = 0, d_db_bytes = 0;
+    int* d_idx = nullptr;
+    float* d_dist = nullptr;
+};
+
+namespace {
+
+constexpr int kMaxSplit = 64;
+
+void free_matcher(mif_matcher* m)
+{
+    (void)hipFree(m->qn); (void)hipFree(m->dn); (void)hipFree(m->part_s); (void)hipFree(m->part_i);
+    (void)hipFree(m->d_q); (void)hipFree(m->d_db); (void)hipFree(m->d_idx); (void)hipFree(m->d_dist);
+}
+
+int pick_split(int nq, int nd)
+{
+    // enough blocks to cover the chip a few times over, but no split smaller than 8 chunks
+    const int qblocks = (nq + kQT * kWaves - 1) / (kQT * kWaves);
+    const int chunks = (nd + kDC - 1) / kDC;
+    int split = (1024 + qblocks - 1) / qblocks;
+    split = std::min(split, std::max(1, chunks / 8));
+    return std::max(1, std::min(split, kMaxSplit));
+}
+
+int match_device(mif_matcher* m, const float* d_q, int nq, const int32_t* d_nq, const float* d_db, int nd,
+                 const int32_t* d_nd, int dim, int ld, int32_t* d_idx2, float* d_dist2, hipStream_t st)
+{
+    if (nq < 0 || nd < 0 || nq > m->max_q || nd > m->max_d) {
+        mif::set_error("match: %d x %d rows exceed the matcher's capacity %d x %d", nq, nd, m->max_q, m->max_d);
+        return MIF_ERR_CAPACITY;
+    }
+    if (dim < 1 || dim > 128 || ld < dim) {
+        mif::set_error("match: dim must be 1..128 and ld >= dim (got dim %d, ld %d)", dim, ld);
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    if (nq == 0) return MIF_OK;
+    const int nsplit = pick_split(nq, nd);
+    if (nd > 0) {
+        hipLaunchKernelGGL(k_row_norms, dim3((nd + 255) / 256), dim3(256), 0, st, d_db, nd, d_nd, dim, ld, m->dn);
+        hipLaunchKernelGGL(k_row_norms, dim3((nq + 255) / 256), dim3(256), 0, st, d_q, nq, d_nq, dim, ld, m->qn);
+        dim3 grid((nq + kQT * kWaves - 1) / (kQT * kWaves), nsplit);
+        if (dim <= 64)
+            hipLaunchKernelGGL((k_match_partial<32>), grid, dim3(256), 0, st, d_q, nq, d_nq, d_db, nd, d_nd, dim, ld,
+                               (const float*)m->qn, (const float*)m->dn, nsplit, m->part_s, m->part_i);
+        else
+            hipLaunchKernelGGL((k_match_partial<64>), grid, dim3(256), 0, st, d_q, nq, d_nq, d_db, nd, d_nd, dim, ld,
+                               (const float*)m->qn, (const float*)m->dn, nsplit, m->part_s, m->part_i);
+    }
+    hipLaunchKernelGGL(k_match_finalize, dim3((nq + 127) / 128), dim3(128), 0, st, d_q, nq, d_nq, d_db, nd, d_nd, dim,
+                       ld, nsplit, (const float*)m->part_s, (const int*)m->part_i, d_idx2, d_dist2);
+    MIF_HIP(hipGetLastError());
+    return MIF_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int mif_match_create(int device, int max_query, int max_database, mif_matcher** out)
+{
+    if (!out) return MIF_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (max_query < 1 || max_database < 1) {
+        mif::set_error("mif_match_create: capacities must be positive");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(device);
+    if (!guard.ok) { mif::set_error("mif_match_create: cannot select device %d", device); return MIF_ERR_HIP; }
+    mif_matcher* m = new mif_matcher();
+    m->device = device; m->max_q = max_query; m->max_d = max_database;
+    m->max_split = kMaxSplit;
+    auto fail = [&](hipError_t e) {
+        mif::set_error("mif_match_create: %s", hipGetErrorString(e));
+        free_matcher(m);
+        delete m;
+        return MIF_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&m->qn, (size_t)max_query * sizeof(float))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&m->dn, (size_t)max_database * sizeof(float))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&m->part_s, (size_t)kMaxSplit * max_query * 2 * sizeof(float))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&m->part_i, (size_t)kMaxSplit * max_query * 2 * sizeof(int))) != hipSuccess) return fail(e);
+    *out = m;
+    return MIF_OK;
+}
+
+int mif_match_destroy(mif_matcher* m)
+{
+    if (!m) return MIF_OK;
+    mif::DeviceGuard guard(m->device);
+    (void)hipDeviceSynchronize();
+    free_matcher(m);
+    delete m;
+    return MIF_OK;
+}
+
+int mif_match_top2_device(mif_matcher* m, const float* d_q, int nq, const int32_t* d_nq, const float* d_db, int nd,
+                          const int32_t* d_nd, int dim, int ld, int32_t* d_idx2, float* d_dist2, void* stream)
+{
+    if (!m || !d_idx2 || !d_dist2 || (nq > 0 && !d_q) || (nd > 0 && !d_db)) {
+        mif::set_error("mif_match_top2_device: NULL argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(m->device);
+    return match_device(m, d_q, nq, d_nq, d_db, nd, d_nd, dim, ld, d_idx2, d_dist2, (hipStream_t)stream);
+}
+
+int mif_match_top2(mif_matcher* m, const float* q, int nq, const float* db, int nd, int dim, int ld, int32_t* idx2,
+                   float* dist2)
+{
+    if (!m || !idx2 || !dist2 || (nq > 0 && !q) || (nd > 0 && !db)) {
+        mif::set_error("mif_match_top2: NULL argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    if (nq < 0 || nd < 0 || nq > m->max_q || nd > m->max_d) {
+        mif::set_error("mif_match_top2: %d x %d rows exceed the matcher's capacity %d x %d", nq, nd, m->max_q,
+                       m->max_d);
+        return MIF_ERR_CAPACITY;
+    }
+    if (nq == 0) return MIF_OK;
+    mif::DeviceGuard guard(m->device);
+    const size_t qb = (size_t)nq * ld * sizeof(float), db_b = (size_t)std::max(nd, 1) * ld * sizeof(float);
+    if (qb > m->d_q_bytes) {
+        (void)hipFree(m->d_q); m->d_q = nullptr; m->d_q_bytes = 0;
+        MIF_HIP(hipMalloc(&m->d_q, qb));
+        m->d_q_bytes = qb;
+    }
+    if (db_b > m->d_db_bytes) {
+        (void)hipFree(m->d_db); m->d_db = nullptr; m->d_db_bytes = 0;
+        MIF_HIP(hipMalloc(&m->d_db, db_b));
+        m->d_db_bytes = db_b;
+    }
+    if (!m->d_idx) {
+        MIF_HIP(hipMalloc(&m->d_idx, (size_t)m->max_q * 2 * sizeof(int)));
+        MIF_HIP(hipMalloc(&m->d_dist, (size_t)m->max_q * 2 * sizeof(float)));
+    }
+    MIF_HIP(hipMemcpy(m->d_q, q, qb, hipMemcpyHostToDevice));
+    if (nd > 0) MIF_HIP(hipMemcpy(m->d_db, db, (size_t)nd * ld * sizeof(float), hipMemcpyHostToDevice));
+    const int rc = match_device(m, m->d_q, nq, nullptr, m->d_db, nd, nullptr, dim, ld, m->d_idx, m->d_dist, nullptr);
+    if (rc != MIF_OK) return rc;
+    MIF_HIP(hipDeviceSynchronize());
+    MIF_HIP(hipMemcpy(idx2, m->d_idx, (size_t)nq * 2 * sizeof(int), hipMemcpyDeviceToHost));
+    MIF_HIP(hipMemcpy(dist2, m->d_dist, (size_t)nq * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    return MIF_OK;
+}
+
+} // extern "C"

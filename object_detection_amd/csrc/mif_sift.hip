@@ -1,0 +1,1009 @@
+// GPU-resident SIFT for MI355X (gfx950): Gaussian scale space, DoG, extremum
+// detection with sub-pixel refinement, orientation and 128-d descriptors.
+//
+// Replaces the reference's OpenCL kernels and their launch plan
+// (SIFT/sift.cpp:41-766 kernels, 1119-1282 call_async_detector / call_async,
+// 1856-1916 extract_features) with one stream-ordered sequence per frame that
+// never returns to the host between stages:
+//
+//   gray | decimate -> 6 x blur_level (H + V + DoG fused, LDS tiled)
+//        -> detect (ballot bitmask + per-row counts) -> scan -> emit (raster order)
+//        -> orientation -> descriptor + normalise
+//
+// Arithmetic contract: every value is computed with the same sequence of IEEE
+// fp32/fp64 operations on every run and every machine (-ffp-contract=off, fused
+// operations spelled fmaf, transcendental functions from mif_math.h), so
+// keypoint counts, positions, orientations and descriptors are reproducible bit
+// for bit and independent of scheduling.
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include "mif_common.h"
+#include "mif_math.h"
+
+namespace {
+
+constexpr int kOctaves = MIF_SIFT_OCTAVES;
+constexpr int kLevels = MIF_SIFT_LEVELS;
+constexpr int kIntervals = 3;      // _SIFT_INTVLS, sift.cpp:17
+constexpr int kBorder = 5;         // _SIFT_IMG_BORDER, sift.cpp:22
+constexpr int kInterpSteps = 5;    // _SIFT_MAX_INTERP_STEPS, sift.cpp:18
+constexpr int kOriBins = 36;       // _SIFT_ORI_HIST_BINS, sift.cpp:26
+constexpr int kOriLanes = 16;      // _SIFT_ORIENT_GPU_BLOCKSIZE, sift.cpp:27
+constexpr int kMaxTaps = 24;
+
+// Kernel constants as the reference's kernels see them: the host prints them
+// into -D options with 6 significant digits and OpenCL C parses them as double
+// literals (sift.cpp:1372-1394).
+#define K_SIGMA 1.6
+#define K_CONTR_THR_1 0.0108333
+#define K_CONTR_THR 0.065
+#define K_ORI_SIG_FCTR 1.5
+#define K_ORI_RADIUS 4.5
+#define K_ORI_PEAK_RATIO 0.8
+#define K_DESCR_MAG_THR 0.2
+#define K_INT_DESCR_FCTR 512.0
+#define K_M_PI 3.14159265358979323846
+#define K_M_PI2 (2.0 * K_M_PI)
+#define K_RPI (4.0 / K_M_PI)
+
+struct Taps {
+    float t[kMaxTaps];
+};
+
+// counts[] layout in device memory
+enum { CNT_OCT0 = 0, CNT_TOTAL = 3, CNT_RAW0 = 4, CNT_STATUS = 7, CNT_WORDS = 8 };
+
+// ---------------------------------------------------------------- base image
+
+// sift.cpp:901-913 copy_pixels_1ch8_to_1ch32 (a host loop in the reference)
+__global__ void k_gray_u8(const uint8_t* __restrict__ in, float* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i] / 255.0f;
+}
+
+// sift.cpp:55-72 kColor_interleaved_ch
+__global__ void k_gray_bgr(const uint8_t* __restrict__ in, float* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float b = (float)in[3 * i], g = (float)in[3 * i + 1], r = (float)in[3 * i + 2];
+    const float cb = (float)0.114, cg = (float)0.587, cr = (float)0.299;
+    const float val_scale = (float)0.0039215686;
+    out[i] = (b * cb + g * cg + r * cr) * val_scale;
+}
+
+// sift.cpp:113-132 kDown_pyramid with wo = 2w, d = 2, ss_img_id = 3
+// (sift.cpp:1187-1191). `src` is the previous octave's whole pyramid; the
+// source offset 3*(2w)*(2h) and row stride 2w are kept as written, which differs
+// from the previous octave's true geometry when its width or height is odd.
+__global__ void k_decimate(const float* __restrict__ src, float* __restrict__ dst, int w, int h)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const int wo = 2 * w;
+    const int offset = kIntervals * w * 2 * h * 2;
+    dst[y * w + x] = src[(y * 2) * wo + x * 2 + offset];
+}
+
+// ---------------------------------------------------------------- blur level
+//
+// One launch per pyramid level: dst = V(H(src)) with the level's taps, and
+// (level >= 1) dog = dst - src, i.e. kBlurH + kBlurV + kDiff of the reference
+// (sift.cpp:213-261) in one pass over HBM: 4 B read + 4 or 8 B written per
+// pixel instead of 16 + 12.
+//
+// Both 1-D passes apply taps 0 .. 2*FR-1 only (the reference's loops stop one
+// short of the filter width, sift.cpp:222,238) in ascending order as an fmaf
+// chain starting from 0, with zeros outside the image.
+//
+// A block owns a TW x TH output tile. The (TW+2FR-1) x (TH+2FR-1) input window
+// is staged TRANSPOSED in LDS so that the horizontal pass can run with lanes
+// along y and a register sliding window along x (P outputs per work item),
+// and writes its result row-major so that the vertical pass runs with lanes
+// along x and a sliding window along y (R outputs per work item). Both passes
+// therefore read LDS with unit stride across lanes (conflict free) and touch
+// each staged value (P+2FR-1)/P resp. (R+2FR-1)/R times instead of 2FR times.
+template <int FR, int TW, int TH, bool DOG>
+__global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ src, float* __restrict__ dst,
+                                                    float* __restrict__ dog, int w, int h, Taps taps)
+{
+    constexpr int P = 8, R = 8;
+    constexpr int EW = TW + 2 * FR - 1;          // staged columns
+    constexpr int EH = TH + 2 * FR - 1;          // staged rows
+    constexpr int PT = (EH % 2 == 0) ? EH + 1 : EH;   // odd pitch of the transposed input
+    constexpr int PH = TW + 1;                   // odd pitch of the H-pass result
+    constexpr int NT = 2 * FR;                   // taps applied
+    static_assert(TW % P == 0 && TH % R == 0, "tile must be a multiple of the register windows");
+    static_assert(NT <= kMaxTaps, "too many taps");
+
+    __shared__ float s_in[EW * PT];
+    __shared__ float s_h[EH * PH];
+
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW;
+    const int y0 = blockIdx.y * TH;
+
+    // stage the input window, zero outside the image
+    for (int idx = tid; idx < EW * EH; idx += 256) {
+        const int ly = idx / EW;
+        const int lx = idx - ly * EW;
+        const int gx = x0 - FR + lx;
+        const int gy = y0 - FR + ly;
+        float v = 0.0f;
+        if (gx >= 0 && gx < w && gy >= 0 && gy < h) v = src[(size_t)gy * w + gx];
+        s_in[lx * PT + ly] = v;
+    }
+    __syncthreads();
+
+    // horizontal pass: lanes along the staged rows
+    for (int item = tid; item < EH * (TW / P); item += 256) {
+        const int chunk = item / EH;
+        const int row = item - chunk * EH;
+        float win[P + NT - 1];
+#pragma unroll
+        for (int j = 0; j < P + NT - 1; j++) win[j] = s_in[(chunk * P + j) * PT + row];
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NT; k++) acc = __builtin_fmaf(taps.t[k], win[p + k], acc);
+            s_h[row * PH + chunk * P + p] = acc;
+        }
+    }
+    __syncthreads();
+
+    // vertical pass: lanes along x
+    for (int item = tid; item < TW * (TH / R); item += 256) {
+        const int yc = item / TW;
+        const int x = item - yc * TW;
+        float win[R + NT - 1];
+#pragma unroll
+        for (int j = 0; j < R + NT - 1; j++) win[j] = s_h[(yc * R + j) * PH + x];
+        const int gx = x0 + x;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < NT; k++) acc = __builtin_fmaf(taps.t[k], win[r + k], acc);
+            const int gy = y0 + yc * R + r;
+            if (gx < w && gy < h) {
+                dst[(size_t)gy * w + gx] = acc;
+                if (DOG) dog[(size_t)gy * w + gx] = acc - s_in[(x + FR) * PT + (yc * R + r + FR)];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ detector
+
+// sift.cpp:292-322 LOC_EXTREMUM: the previous image is tested at (y-1,x-1)
+// twice and never at (y-1,x+1); the centre of the current image is skipped.
+template <bool GT>
+__device__ __forceinline__ bool loc_extremum(float v, const float* __restrict__ p, const float* __restrict__ c,
+                                             const float* __restrict__ n, int w, int y, int x)
+{
+#define CMP(img, yy, xx) (GT ? (v > img[(yy) * w + (xx)]) : (v < img[(yy) * w + (xx)]))
+    return CMP(p, y, x - 1) && CMP(p, y, x) && CMP(p, y, x + 1) && CMP(p, y + 1, x - 1) && CMP(p, y + 1, x) &&
+           CMP(p, y + 1, x + 1) && CMP(p, y - 1, x - 1) && CMP(p, y - 1, x) &&
+           CMP(c, y, x - 1) && CMP(c, y, x + 1) && CMP(c, y + 1, x - 1) && CMP(c, y + 1, x) &&
+           CMP(c, y + 1, x + 1) && CMP(c, y - 1, x - 1) && CMP(c, y - 1, x) && CMP(c, y - 1, x + 1) &&
+           CMP(n, y, x - 1) && CMP(n, y, x) && CMP(n, y, x + 1) && CMP(n, y + 1, x - 1) && CMP(n, y + 1, x) &&
+           CMP(n, y + 1, x + 1) && CMP(n, y - 1, x - 1) && CMP(n, y - 1, x) && CMP(n, y - 1, x + 1);
+#undef CMP
+}
+
+// sift.cpp:265-417 kDetector for the pixel (x, y) of DoG level s in octave o.
+// Returns true when the reference would append a feature; *out is that feature.
+// The refinement steps tx, ty, ts but keeps reading the same three DoG images,
+// as the reference does.
+__device__ bool detect_pixel(const float* __restrict__ dp, const float* __restrict__ dc,
+                             const float* __restrict__ dn, int w, int h, int s, int o, int x, int y, float4* out)
+{
+    if (y <= kBorder || y >= h - kBorder || x <= kBorder || x >= w - kBorder) return false;
+    float cur = dc[y * w + x];
+    if ((double)mif_fabsf(cur) <= K_CONTR_THR_1) return false;
+    if (!(loc_extremum<true>(cur, dp, dc, dn, w, y, x) || loc_extremum<false>(cur, dp, dc, dn, w, y, x)))
+        return false;
+
+    float Dxx = 0.f, Dyy = 0.f, Dxy = 0.f;
+    float gx = 0.f, gy = 0.f, gz = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
+    int tx = x, ty = y, ts = s, iter;
+    for (iter = 0; iter < kInterpSteps; iter++) {
+        const float c00 = dc[ty * w + tx];
+        const float cxp = dc[ty * w + tx + 1], cxm = dc[ty * w + tx - 1];
+        const float cyp = dc[(ty + 1) * w + tx], cym = dc[(ty - 1) * w + tx];
+        const float n00 = dn[ty * w + tx], p00 = dp[ty * w + tx];
+        gx = 0.5f * (cxp - cxm);
+        gy = 0.5f * (cyp - cym);
+        gz = 0.5f * (n00 - p00);
+        Dxx = cxp - 2.0f * c00 + cxm;
+        Dyy = cyp - 2.0f * c00 + cym;
+        const float Dss = n00 - 2.0f * c00 + p00;
+        Dxy = 0.25f * (dc[(ty + 1) * w + tx + 1] + dc[(ty - 1) * w + tx - 1] - dc[(ty + 1) * w + tx - 1] -
+                       dc[(ty - 1) * w + tx + 1]);
+        const float Dxs = 0.25f * (dn[ty * w + tx + 1] + dp[ty * w + tx - 1] - dn[ty * w + tx - 1] -
+                                   dp[ty * w + tx + 1]);
+        const float Dys = 0.25f * (dn[(ty + 1) * w + tx] + dp[(ty - 1) * w + tx] - dp[(ty + 1) * w + tx] -
+                                   dn[(ty - 1) * w + tx]);
+        // adjugate of the 3x3 Hessian, rows as in sift.cpp:356-366
+        float a0 = Dyy * Dss - Dys * Dys;
+        float b0 = Dys * Dxs - Dxy * Dss;
+        float c0 = Dxy * Dys - Dyy * Dxs;
+        const float det = Dxx * a0 + Dxy * b0 + Dxs * c0;
+        float a1 = Dxs * Dys - Dxy * Dss;
+        float a2 = Dxy * Dys - Dxs * Dyy;
+        float b1 = Dxx * Dss - Dxs * Dxs;
+        float b2 = Dxs * Dxy - Dxx * Dys;
+        float c1 = Dxy * Dxs - Dxx * Dys;
+        float c2 = Dxx * Dyy - Dxy * Dxy;
+        if (det == 0.0f) return false;
+        const float dv = -1.0f / det;
+        a0 *= dv; a1 *= dv; a2 *= dv;
+        b0 *= dv; b1 *= dv; b2 *= dv;
+        c0 *= dv; c1 *= dv; c2 *= dv;
+        ox = a0 * gx + a1 * gy + a2 * gz;
+        oy = b0 * gx + b1 * gy + b2 * gz;
+        oz = c0 * gx + c1 * gy + c2 * gz;
+        if (mif_fabsf(ox) < 0.5f && mif_fabsf(oy) < 0.5f && mif_fabsf(oz) < 0.5f) break;
+        tx += (int)mif_roundf(ox);
+        if (tx < kBorder || tx >= w - kBorder) return false;
+        ty += (int)mif_roundf(oy);
+        if (ty < kBorder || ty >= h - kBorder) return false;
+        ts += (int)mif_roundf(oz);
+        if (ts < 1 || ts > kIntervals) return false;
+    }
+    if (iter >= kInterpSteps) return false;
+
+    const float trH = Dxx + Dyy;
+    const float detH = Dxx * Dyy - Dxy * Dxy;
+    if ((double)mif_fabsf(detH) <= 1e-8) return false;
+    if ((trH * trH) / detH >= 12.0f) return false;    // (10+1)*(10+1)/10 in integers, sift.cpp:398
+
+    cur = ts == 1 ? dp[ty * w + tx] : ts == 2 ? dc[ty * w + tx] : dn[ty * w + tx];   // sift.cpp:400
+    const float contrast = cur + 0.5f * (gx * ox + gy * oy + gz * oz);
+    if (!(mif_fabsf(contrast) > (float)(K_CONTR_THR / kIntervals))) return false;
+
+    const float p2o = mif_pow2i(o);
+    out->x = ((float)tx + ox) * p2o;
+    out->y = ((float)ty + oy) * p2o;
+    out->z = (float)(K_SIGMA * (double)mif_exp2f(((float)ts + oz) / (float)kIntervals));
+    out->w = (float)ts;
+    return true;
+}
+
+// Detection pass: grid (ceil(w/256), h, 3 levels), 256 threads. Every wave
+// tests 64 consecutive pixels of one row and stores its ballot as one 64-bit
+// word of the acceptance bitmask; row totals are accumulated with integer
+// atomics (order independent).
+__global__ __launch_bounds__(256) void k_detect(const float* __restrict__ dog, unsigned long long* __restrict__ mask,
+                                                int* __restrict__ rowcnt, int w, int h, int words, int o)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    const int s = blockIdx.z + 1;
+    const size_t items = (size_t)w * h;
+    bool found = false;
+    if (x < w) {
+        float4 kp;
+        found = detect_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o, x, y, &kp);
+    }
+    const unsigned long long m = __ballot(found);
+    const int word = x >> 6;                      // uniform over the wave
+    if ((threadIdx.x & 63) == 0 && word < words) {
+        const int r = (s - 1) * h + y;
+        mask[(size_t)r * words + word] = m;
+        if (m) atomicAdd(&rowcnt[r], __popcll(m));
+    }
+}
+
+// Exclusive scan of the per-row counts (rows ordered level-major, then y),
+// the octave's keypoint count (cut at max_features = items/100, sift.cpp:1356,
+// 408) and its raw total. One block of 1024 threads.
+__global__ __launch_bounds__(1024) void k_scan_rows(const int* __restrict__ rowcnt, int* __restrict__ rowoff,
+                                                    int rows, int maxf, int o, int* __restrict__ counts)
+{
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (rows + 1023) / 1024;
+    const int lo = tid * per;
+    const int hi = min(rows, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += rowcnt[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = (tid >= d) ? s_part[tid - d] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+    for (int i = lo; i < hi; i++) {
+        rowoff[i] = run;
+        run += rowcnt[i];
+    }
+    if (tid == 1023) {
+        const int total = s_part[1023];
+        const int n = min(total, maxf);
+        counts[CNT_OCT0 + o] = n;
+        counts[CNT_RAW0 + o] = total;
+        int cum = n;
+        for (int i = 0; i < o; i++) cum += counts[CNT_OCT0 + i];
+        counts[CNT_TOTAL] = cum;
+    }
+}
+
+__device__ __forceinline__ int octave_base(const int* counts, int o)
+{
+    int b = 0;
+    for (int i = 0; i < o; i++) b += counts[CNT_OCT0 + i];
+    return b;
+}
+
+// Emission pass: one wave per (level, row). Accepted pixels are re-refined (the
+// refinement is a pure function of the DoG stack) and written at
+// base(octave) + rowoff + rank-in-row, i.e. in raster order.
+__global__ __launch_bounds__(256) void k_emit(const float* __restrict__ dog,
+                                              const unsigned long long* __restrict__ mask,
+                                              const int* __restrict__ rowcnt, const int* __restrict__ rowoff, int w,
+                                              int h, int words, int o, int maxf, const int* __restrict__ counts,
+                                              float4* __restrict__ kp)
+{
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= kIntervals * h) return;
+    if (rowcnt[r] == 0) return;
+    const int s = r / h + 1;
+    const int y = r - (s - 1) * h;
+    const size_t items = (size_t)w * h;
+    const int base = octave_base(counts, o);
+    int pos = rowoff[r];
+    for (int word = 0; word < words; word++) {
+        const unsigned long long m = mask[(size_t)r * words + word];
+        if (m == 0) continue;
+        if ((m >> lane) & 1ull) {
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            const int p = pos + rank;
+            if (p < maxf) {
+                float4 out;
+                detect_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o,
+                             word * 64 + lane, y, &out);
+                kp[base + p] = out;
+            }
+        }
+        pos += __popcll(m);
+    }
+}
+
+// --------------------------------------------------------------- orientation
+
+// sift.cpp:431-582 kOrientation. A block serves four keypoints, 16 lanes each,
+// exactly the reference's work-group of 16: lane l accumulates window pixels
+// l, l+16, ... into its private 36-bin histogram, the 16 histograms are summed
+// with the reference's tree (8, 4, 2, 1) and lane 0 smooths and picks the last
+// qualifying peak.
+__global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ kp, const float* __restrict__ pyr,
+                                                    int w, int h, int o, const int* __restrict__ counts,
+                                                    float* __restrict__ orient)
+{
+    __shared__ float s_hist[4][kOriLanes][kOriBins + 1];
+    const int grp = threadIdx.x >> 4;
+    const int lid = threadIdx.x & 15;
+    const int n = counts[CNT_OCT0 + o];
+    const int g = blockIdx.x * 4 + grp;
+    const bool active = g < n;
+    const int gi = octave_base(counts, o) + g;
+    float* hist = s_hist[grp][lid];
+    for (int i = 0; i < kOriBins; i++) hist[i] = 0.0f;
+
+    int x = 0, y = 0;
+    if (active) {
+        const float4 f = kp[gi];
+        const float exp_denom = (float)((double)f.z * K_ORI_SIG_FCTR);
+        const int rad = (int)mif_round(K_ORI_RADIUS * (double)f.z);
+        const float exp_factor = -0.5f / (exp_denom * exp_denom);
+        const int sq_thres = rad * rad;
+        const int offset_py = (int)((float)(w * h) * f.w);
+        const float p2o = mif_pow2i(o);
+        x = (int)(f.x / p2o);
+        y = (int)(f.y / p2o);
+        const int xmin = max(1, x - rad), ymin = max(1, y - rad);
+        const int xmax = min(w - 2, x + rad), ymax = min(h - 2, y + rad);
+        const int wx = xmax - xmin + 1, hy = ymax - ymin + 1;
+        const int loops = wx * hy;
+        const float* img = pyr + offset_py;
+        for (int i = lid; i < loops; i += kOriLanes) {
+            const int yy = i / wx + ymin;
+            const int xx = i % wx + xmin;
+            if (xx > 0 && xx < w - 1 && yy > 0 && yy < h - 1) {
+                float dx = img[yy * w + xx + 1] - img[yy * w + xx - 1];
+                float dy = img[(yy - 1) * w + xx] - img[(yy + 1) * w + xx];
+                const float grad = __builtin_sqrtf(dx * dx + dy * dy);
+                const float theta = mif_atan2f(dy, dx);
+                dx = (float)(xx - x);
+                dy = (float)(yy - y);
+                const int sq_dist = (int)(dx * dx + dy * dy);
+                if (sq_dist > sq_thres) continue;
+                int bin = (int)mif_round((kOriBins * ((double)theta + K_M_PI)) / K_M_PI2);
+                bin = (bin < kOriBins) ? bin : 0;
+                hist[bin] += grad * mif_expf((float)sq_dist * exp_factor);
+            }
+        }
+    }
+    __syncthreads();
+    // tree reduction of the 16 private histograms, association as sift.cpp:509-522
+    for (int i = lid; i < kOriBins; i += kOriLanes) {
+        float v[kOriLanes];
+#pragma unroll
+        for (int l = 0; l < kOriLanes; l++) v[l] = s_hist[grp][l][i];
+#pragma unroll
+        for (int l = 0; l < 8; l++) v[l] += v[l + 8];
+#pragma unroll
+        for (int l = 0; l < 4; l++) v[l] += v[l + 4];
+#pragma unroll
+        for (int l = 0; l < 2; l++) v[l] += v[l + 2];
+        v[0] += v[1];
+        s_hist[grp][0][i] = v[0];     // only this lane touches column i
+    }
+    __syncthreads();
+    if (!active || lid != 0) return;
+
+    float* hs = s_hist[grp][0];
+    for (int j = 0; j < 2; j++) {       // two [1/4 1/2 1/4] passes in double, sift.cpp:531-543
+        const float h0 = hs[0];
+        float hp = hs[kOriBins - 1];
+        for (int i = 0; i < kOriBins; i++) {
+            const float hc = hs[i];
+            const float hn = (i + 1 == kOriBins) ? h0 : hs[i + 1];
+            hs[i] = (float)(0.25 * (double)hp + 0.5 * (double)hc + 0.25 * (double)hn);
+            hp = hc;
+        }
+    }
+    float v = hs[0];
+    for (int i = 1; i < kOriBins; i++)
+        if (hs[i] > v) v = hs[i];
+    v = (float)(K_ORI_PEAK_RATIO * (double)v);
+    float result = -1.0f;               // _ORIENT_INIT_CONST
+    for (int i = 0; i < kOriBins; i++) {
+        const float hc = hs[i];
+        const float hp = hs[(i == 0) ? (kOriBins - 1) : (i - 1)];
+        const float hn = hs[(i + 1) % kOriBins];
+        if (hc >= v && hc > hn && hc > hp) {
+            float fbin = (float)((double)(float)i +
+                                 ((double)(0.5f * (hp - hn)) / ((double)hp - 2.0 * (double)hc + (double)hn)));
+            fbin = (fbin < 0.0f) ? (fbin + (float)kOriBins)
+                                 : ((fbin >= (float)kOriBins) ? (fbin - (float)kOriBins) : fbin);
+            result = (float)(((K_M_PI2 * (double)fbin) / kOriBins) - K_M_PI);
+        }
+    }
+    orient[gi] = result;
+}
+
+// ---------------------------------------------------------------- descriptor
+
+__device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+// sift.cpp:585-709 kDescriptor fused with sift.cpp:712-765 kNormalize. One
+// block of 128 threads per keypoint: 16 cells x 8 lanes, lane l of a cell
+// accumulates window pixels l, l+8, ... into a private 9-bin histogram; bin 8
+// folds into bin 0 and the 8 histograms of a cell are summed in lane order.
+// Normalisation sums the 128 squares sequentially, as the reference's
+// one-thread-per-keypoint kernel does.
+__global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ kp, const float* __restrict__ orient,
+                                                    const float* __restrict__ pyr, int w, int h, int o,
+                                                    const int* __restrict__ counts, float* __restrict__ desc)
+{
+    __shared__ float s_des[16][8][9];
+    __shared__ float s_val[128];
+    __shared__ float s_sq[128];
+    __shared__ float s_norm;
+    const int n = counts[CNT_OCT0 + o];
+    if ((int)blockIdx.x >= n) return;                  // uniform over the block
+    const int gi = octave_base(counts, o) + blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lid = tid & 7;
+    const int bid = tid >> 3;
+    const int ix = bid & 3, iy = bid >> 2;
+    float* d = s_des[bid][lid];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = 0.0f;
+
+    const float4 f = kp[gi];
+    const float p2o = mif_pow2i(o);
+    const int x = (int)(f.x / p2o);
+    const int y = (int)(f.y / p2o);
+    const float* img = pyr + (int)((float)(w * h) * f.w);
+    const float ang = -orient[gi];
+    const float spt = (float)fabs((double)f.z * 3.0);
+    float sn, cs;
+    mif_sincosf(ang, &sn, &cs);
+    const float cspt = cs * spt, sspt = sn * spt;
+    const float crspt = cs / spt, srspt = sn / spt;
+    const float offx = (float)ix - 1.5f, offy = (float)iy - 1.5f;
+    const float ptx = cspt * offx - sspt * offy + (float)x;
+    const float pty = cspt * offy + sspt * offx + (float)y;
+    const float bsz = mif_fabsf(cspt) + mif_fabsf(sspt);
+    // MAXV / MINV compare an int with a float in float and truncate back (sift.cpp:641-644)
+    const float fxmin = __builtin_floorf(ptx - bsz), fymin = __builtin_floorf(pty - bsz);
+    const float fxmax = __builtin_floorf(ptx + bsz), fymax = __builtin_floorf(pty + bsz);
+    const int xmin = (1.0f >= fxmin) ? 1 : (int)fxmin;
+    const int ymin = (1.0f >= fymin) ? 1 : (int)fymin;
+    const int xmax = ((float)(w - 2) <= fxmax) ? (w - 2) : (int)fxmax;
+    const int ymax = ((float)(h - 2) <= fymax) ? (h - 2) : (int)fymax;
+    const int wx = xmax - xmin + 1, hy = ymax - ymin + 1;
+    // a window that is empty in both directions has a positive wx*hy in the
+    // reference and would index outside the image; it is treated as empty
+    const int loops = (wx > 0 && hy > 0) ? wx * hy : 0;
+    for (int i = lid; i < loops; i += 8) {
+        const int yy = i / wx + ymin;
+        const int xx = i % wx + xmin;
+        float dx = (float)xx - ptx;
+        float dy = (float)yy - pty;
+        const float nx = crspt * dx + srspt * dy;
+        const float ny = crspt * dy - srspt * dx;
+        const float nxn = mif_fabsf(nx), nyn = mif_fabsf(ny);
+        if (nxn < 1.0f && nyn < 1.0f) {
+            dx = img[yy * w + xx + 1] - img[yy * w + xx - 1];
+            dy = img[(yy + 1) * w + xx] - img[(yy - 1) * w + xx];
+            const float mod = __builtin_sqrtf(dx * dx + dy * dy);
+            float th = mif_atan2f(dy, dx);
+            const float dnx = nx + offx, dny = ny + offy;
+            const float ww = mif_expf(-0.125f * (dnx * dnx + dny * dny));
+            const float wwx = (float)(1.0 - (double)nxn);
+            const float wwy = (float)(1.0 - (double)nyn);
+            const float wgt = ww * wwx * wwy * mod;
+            th -= ang;
+            while (th < 0.0f) th = (float)((double)th + K_M_PI2);
+            while ((double)th >= K_M_PI2) th = (float)((double)th - K_M_PI2);
+            const float tth = (float)((double)th * K_RPI);
+            const int fo0 = (int)__builtin_floorf(tth);
+            const float do0 = tth - (float)fo0;
+            const int fo = fo0 % 8;
+            d[fo] += (1.0f - do0) * wgt;
+            d[fo + 1] += do0 * wgt;
+        }
+    }
+    d[0] += d[8];
+    __syncthreads();
+    float bin = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) bin += s_des[bid][i][lid];
+
+    // normalise -> clamp 0.2 -> normalise -> x512 -> clamp 255
+    s_val[tid] = bin;
+    s_sq[tid] = bin * bin;
+    __syncthreads();
+    if (tid == 0) {
+        float nrm = 0.0f;
+        for (int i = 0; i < 128; i++) nrm += s_sq[i];
+        s_norm = 1.0f / __builtin_sqrtf(nrm);
+    }
+    __syncthreads();
+    float v0 = clampf(s_val[tid] * s_norm, 0.0f, (float)K_DESCR_MAG_THR);
+    s_sq[tid] = v0 * v0;
+    __syncthreads();
+    if (tid == 0) {
+        float nrm = 0.0f;
+        for (int i = 0; i < 128; i++) nrm += s_sq[i];
+        s_norm = 1.0f / __builtin_sqrtf(nrm);
+    }
+    __syncthreads();
+    const float v1 = (float)K_INT_DESCR_FCTR * (v0 * s_norm);
+    desc[(size_t)gi * 128 + tid] = clampf(v1, 0.0f, 255.0f);
+}
+
+// After the last octave: status = 0, or -1 when an octave found nothing
+// (sift.cpp:1257-1258); in that case all counts are cleared so that no stage
+// downstream consumes a partial frame.
+__global__ void k_finish(int* counts, int want_desc)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int status = 0;
+    if (want_desc)
+        for (int o = 0; o < kOctaves; o++)
+            if (counts[CNT_RAW0 + o] < 1) status = MIF_ERR_NO_KEYPOINTS;
+    counts[CNT_STATUS] = status;
+    if (status != 0) {
+        for (int o = 0; o < kOctaves; o++) counts[CNT_OCT0 + o] = 0;
+        counts[CNT_TOTAL] = 0;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+
+struct OctaveBuf {
+    int w = 0, h = 0, maxf = 0, words = 0, rows = 0;
+    float* base = nullptr;                 // [h][w] input of level 0
+    float* pyr = nullptr;                  // [6][h][w]
+    float* dog = nullptr;                  // [5][h][w]
+    unsigned long long* mask = nullptr;    // [3*h][words]
+    int* rowcnt = nullptr;                 // [3*h]
+    int* rowoff = nullptr;                 // [3*h]
+};
+
+// Build_separable_filter_cof, sift.cpp:819-889: sigma0 = 1.6, k = 2^(1/3), level
+// s >= 1 uses the incremental sigma sqrt(sig_s^2 - sig_{s-1}^2), radius
+// ceil(3.5 sigma), taps exp(-d^2 / (2 sigma^2)) normalised to sum 1.
+void build_taps(std::vector<float> taps[kLevels], int fr[kLevels])
+{
+    const float sigma0 = 1.6f;
+    const float k = powf(2.0f, 1.0f / kIntervals);
+    float sig[kLevels];
+    sig[0] = sigma0;
+    for (int s = 1; s < kLevels; s++) {
+        const float prev = sigma0 * powf(k, (float)(s - 1));
+        const float next = prev * k;
+        sig[s] = sqrtf(next * next - prev * prev);
+    }
+    for (int s = 0; s < kLevels; s++) {
+        const size_t rad = (size_t)ceilf(3.5f * sig[s]);
+        std::vector<float>& t = taps[s];
+        t.assign(2 * rad + 1, 0.0f);
+        float sum = 0.0f;
+        for (size_t i = 0; i < rad; i++) {
+            const size_t d = rad - i;
+            const float q = (float)(d * d) / (sig[s] * sig[s]);
+            const float v = expf((float)(-0.5 * q));
+            t[i] = t[2 * rad - i] = v;
+            sum += 2 * v;
+        }
+        t[rad] = 1.0f;
+        sum += 1.0f;
+        const float inv = 1.0f / sum;
+        for (float& v : t) v *= inv;
+        fr[s] = (int)rad;
+    }
+}
+
+} // namespace
+
+struct mif_sift {
+    int device = 0, W = 0, H = 0, C = 1, cap = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    OctaveBuf oct[kOctaves];
+    uint8_t* d_pixels = nullptr;           // staging for the host-buffer entry point
+    float4* kp = nullptr;
+    float* orient = nullptr;
+    float* desc = nullptr;
+    int* counts = nullptr;
+    int* h_counts = nullptr;               // pinned
+    std::vector<float> taps[kLevels];
+    int fr[kLevels];
+    Taps ktaps[kLevels];
+    bool frame_done = false;
+};
+
+namespace {
+
+template <int FR>
+void launch_blur_fr(const float* src, float* dst, float* dog, int w, int h, const Taps& t, hipStream_t st)
+{
+    constexpr int TW = 64, TH = 64;
+    dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH);
+    if (dog)
+        hipLaunchKernelGGL((k_blur_level<FR, TW, TH, true>), grid, dim3(256), 0, st, src, dst, dog, w, h, t);
+    else
+        hipLaunchKernelGGL((k_blur_level<FR, TW, TH, false>), grid, dim3(256), 0, st, src, dst, dog, w, h, t);
+}
+
+int launch_blur(int fr, const float* src, float* dst, float* dog, int w, int h, const Taps& t, hipStream_t st)
+{
+    switch (fr) {
+    case 5: launch_blur_fr<5>(src, dst, dog, w, h, t, st); break;
+    case 6: launch_blur_fr<6>(src, dst, dog, w, h, t, st); break;
+    case 7: launch_blur_fr<7>(src, dst, dog, w, h, t, st); break;
+    case 9: launch_blur_fr<9>(src, dst, dog, w, h, t, st); break;
+    case 11: launch_blur_fr<11>(src, dst, dog, w, h, t, st); break;
+    default:
+        mif::set_error("no blur kernel for tap radius %d", fr);
+        return MIF_ERR_UNSUPPORTED;
+    }
+    return MIF_OK;
+}
+
+int enqueue_frame(mif_sift* s, const void* d_pixels, int want_desc)
+{
+    hipStream_t st = s->stream;
+    MIF_HIP(hipEventRecord(s->ev0, st));
+    MIF_HIP(hipMemsetAsync(s->counts, 0, CNT_WORDS * sizeof(int), st));
+    for (int o = 0; o < kOctaves; o++) {
+        OctaveBuf& O = s->oct[o];
+        const int items = O.w * O.h;
+        if (items == 0) continue;
+        if (o == 0) {
+            if (s->C == 3)
+                hipLaunchKernelGGL(k_gray_bgr, dim3((items + 255) / 256), dim3(256), 0, st,
+                                   (const uint8_t*)d_pixels, O.base, items);
+            else
+                hipLaunchKernelGGL(k_gray_u8, dim3((items + 255) / 256), dim3(256), 0, st,
+                                   (const uint8_t*)d_pixels, O.base, items);
+        } else {
+            hipLaunchKernelGGL(k_decimate, dim3((O.w + 255) / 256, O.h), dim3(256), 0, st,
+                               (const float*)s->oct[o - 1].pyr, O.base, O.w, O.h);
+        }
+        // level 0 blurs the base image with sigma 1.6; level l >= 1 blurs level l-1
+        // (sift.cpp:1196-1218) and yields DoG[l-1] = level l - level l-1 (sift.cpp:256-260)
+        for (int l = 0; l < kLevels; l++) {
+            const float* src = (l == 0) ? O.base : O.pyr + (size_t)(l - 1) * items;
+            float* dst = O.pyr + (size_t)l * items;
+            float* dog = (l == 0) ? nullptr : O.dog + (size_t)(l - 1) * items;
+            const int rc = launch_blur(s->fr[l], src, dst, dog, O.w, O.h, s->ktaps[l], st);
+            if (rc != MIF_OK) return rc;
+        }
+        MIF_HIP(hipMemsetAsync(O.rowcnt, 0, (size_t)O.rows * sizeof(int), st));
+        hipLaunchKernelGGL(k_detect, dim3((O.w + 255) / 256, O.h, kIntervals), dim3(256), 0, st,
+                           (const float*)O.dog, O.mask, O.rowcnt, O.w, O.h, O.words, o);
+        hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, st, (const int*)O.rowcnt, O.rowoff, O.rows, O.maxf,
+                           o, s->counts);
+        if (O.maxf > 0) {
+            hipLaunchKernelGGL(k_emit, dim3((O.rows + 3) / 4), dim3(256), 0, st, (const float*)O.dog,
+                               (const unsigned long long*)O.mask, (const int*)O.rowcnt, (const int*)O.rowoff, O.w,
+                               O.h, O.words, o, O.maxf, (const int*)s->counts, s->kp);
+            if (want_desc) {
+                hipLaunchKernelGGL(k_orientation, dim3((O.maxf + 3) / 4), dim3(64), 0, st, (const float4*)s->kp,
+                                   (const float*)O.pyr, O.w, O.h, o, (const int*)s->counts, s->orient);
+                hipLaunchKernelGGL(k_descriptor, dim3(O.maxf), dim3(128), 0, st, (const float4*)s->kp,
+                                   (const float*)s->orient, (const float*)O.pyr, O.w, O.h, o,
+                                   (const int*)s->counts, s->desc);
+            }
+        }
+    }
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, s->counts, want_desc);
+    MIF_HIP(hipGetLastError());
+    MIF_HIP(hipEventRecord(s->ev1, st));
+    s->frame_done = true;
+    return MIF_OK;
+}
+
+void free_all(mif_sift* s)
+{
+    for (int o = 0; o < kOctaves; o++) {
+        OctaveBuf& O = s->oct[o];
+        (void)hipFree(O.base); (void)hipFree(O.pyr); (void)hipFree(O.dog);
+        (void)hipFree(O.mask); (void)hipFree(O.rowcnt); (void)hipFree(O.rowoff);
+    }
+    (void)hipFree(s->d_pixels); (void)hipFree(s->kp); (void)hipFree(s->orient);
+    (void)hipFree(s->desc); (void)hipFree(s->counts);
+    if (s->h_counts) (void)hipHostFree(s->h_counts);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+}
+
+int create_impl(mif_sift* s)
+{
+    MIF_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    MIF_HIP(hipEventCreate(&s->ev0));
+    MIF_HIP(hipEventCreate(&s->ev1));
+    s->cap = 0;
+    for (int o = 0; o < kOctaves; o++) {
+        OctaveBuf& O = s->oct[o];
+        // sift.cpp:1313-1314: size_t = int / std::pow(2, id)
+        O.w = (int)(size_t)(s->W / std::pow(2, o));
+        O.h = (int)(size_t)(s->H / std::pow(2, o));
+        const size_t items = (size_t)O.w * O.h;
+        O.maxf = (int)(items / 100);       // sift.cpp:1356
+        O.words = (O.w + 63) / 64;
+        O.rows = kIntervals * O.h;
+        s->cap += O.maxf;
+        if (items == 0) continue;
+        MIF_HIP(hipMalloc(&O.base, items * sizeof(float)));
+        MIF_HIP(hipMalloc(&O.pyr, items * kLevels * sizeof(float)));
+        MIF_HIP(hipMalloc(&O.dog, items * (kLevels - 1) * sizeof(float)));
+        MIF_HIP(hipMalloc(&O.mask, (size_t)O.rows * O.words * sizeof(unsigned long long)));
+        MIF_HIP(hipMalloc(&O.rowcnt, (size_t)O.rows * sizeof(int)));
+        MIF_HIP(hipMalloc(&O.rowoff, (size_t)O.rows * sizeof(int)));
+    }
+    const size_t cap = (size_t)(s->cap > 0 ? s->cap : 1);
+    MIF_HIP(hipMalloc(&s->d_pixels, (size_t)s->W * s->H * s->C));
+    MIF_HIP(hipMalloc(&s->kp, cap * sizeof(float4)));
+    MIF_HIP(hipMalloc(&s->orient, cap * sizeof(float)));
+    MIF_HIP(hipMalloc(&s->desc, cap * 128 * sizeof(float)));
+    MIF_HIP(hipMalloc(&s->counts, CNT_WORDS * sizeof(int)));
+    MIF_HIP(hipMemset(s->counts, 0, CNT_WORDS * sizeof(int)));
+    MIF_HIP(hipHostMalloc(&s->h_counts, CNT_WORDS * sizeof(int)));
+    build_taps(s->taps, s->fr);
+    for (int l = 0; l < kLevels; l++) {
+        memset(&s->ktaps[l], 0, sizeof(Taps));
+        if ((int)s->taps[l].size() > kMaxTaps) {
+            mif::set_error("filter of level %d has %zu taps, at most %d supported", l, s->taps[l].size(), kMaxTaps);
+            return MIF_ERR_UNSUPPORTED;
+        }
+        for (size_t i = 0; i < s->taps[l].size(); i++) s->ktaps[l].t[i] = s->taps[l][i];
+    }
+    return MIF_OK;
+}
+
+int fetch_counts(mif_sift* s)
+{
+    MIF_HIP(hipMemcpyAsync(s->h_counts, s->counts, CNT_WORDS * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    MIF_HIP(hipStreamSynchronize(s->stream));
+    return MIF_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int mif_sift_create(int device, int width, int height, int channels, int up_scale, mif_sift** out)
+{
+    if (!out) { mif::set_error("mif_sift_create: out is NULL"); return MIF_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || (channels != 1 && channels != 3)) {
+        mif::set_error("mif_sift_create: bad geometry %dx%dx%d", width, height, channels);
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    if ((long long)width * height * 3 >= (1ll << 31)) {
+        mif::set_error("mif_sift_create: image too large for 32-bit pixel indices");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    if (up_scale) {
+        mif::set_error("mif_sift_create: up_scale is not supported");
+        return MIF_ERR_UNSUPPORTED;
+    }
+    mif::DeviceGuard guard(device);
+    if (!guard.ok) { mif::set_error("mif_sift_create: cannot select device %d", device); return MIF_ERR_HIP; }
+    mif_sift* s = new mif_sift();
+    s->device = device; s->W = width; s->H = height; s->C = channels;
+    const int rc = create_impl(s);
+    if (rc != MIF_OK) { free_all(s); delete s; return rc; }
+    *out = s;
+    return MIF_OK;
+}
+
+int mif_sift_destroy(mif_sift* s)
+{
+    if (!s) return MIF_OK;
+    mif::DeviceGuard guard(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    free_all(s);
+    delete s;
+    return MIF_OK;
+}
+
+int mif_sift_octave_info(const mif_sift* s, int octave, int* width, int* height, int* max_features)
+{
+    if (!s || octave < 0 || octave >= kOctaves) { mif::set_error("mif_sift_octave_info: bad argument"); return MIF_ERR_INVALID_ARGUMENT; }
+    if (width) *width = s->oct[octave].w;
+    if (height) *height = s->oct[octave].h;
+    if (max_features) *max_features = s->oct[octave].maxf;
+    return MIF_OK;
+}
+
+int mif_sift_capacity(const mif_sift* s) { return s ? s->cap : MIF_ERR_INVALID_ARGUMENT; }
+
+int mif_sift_enqueue(mif_sift* s, const void* d_pixels, int want_descriptors)
+{
+    if (!s || !d_pixels) { mif::set_error("mif_sift_enqueue: NULL argument"); return MIF_ERR_INVALID_ARGUMENT; }
+    mif::DeviceGuard guard(s->device);
+    return enqueue_frame(s, d_pixels, want_descriptors);
+}
+
+int mif_sift_sync(mif_sift* s)
+{
+    if (!s) return MIF_ERR_INVALID_ARGUMENT;
+    mif::DeviceGuard guard(s->device);
+    MIF_HIP(hipStreamSynchronize(s->stream));
+    return MIF_OK;
+}
+
+int mif_sift_device_results(mif_sift* s, void** d_keypoints, void** d_orientations, void** d_descriptors,
+                            void** d_counts)
+{
+    if (!s) return MIF_ERR_INVALID_ARGUMENT;
+    if (d_keypoints) *d_keypoints = s->kp;
+    if (d_orientations) *d_orientations = s->orient;
+    if (d_descriptors) *d_descriptors = s->desc;
+    if (d_counts) *d_counts = s->counts;
+    return MIF_OK;
+}
+
+void* mif_sift_stream(mif_sift* s) { return s ? (void*)s->stream : nullptr; }
+
+int mif_sift_read_counts(mif_sift* s, int counts[MIF_SIFT_OCTAVES], int raw_counts[MIF_SIFT_OCTAVES])
+{
+    if (!s) return MIF_ERR_INVALID_ARGUMENT;
+    mif::DeviceGuard guard(s->device);
+    const int rc = fetch_counts(s);
+    if (rc != MIF_OK) return rc;
+    for (int o = 0; o < kOctaves; o++) {
+        if (counts) counts[o] = s->h_counts[CNT_OCT0 + o];
+        if (raw_counts) raw_counts[o] = s->h_counts[CNT_RAW0 + o];
+    }
+    return s->h_counts[CNT_STATUS];
+}
+
+int mif_sift_extract(mif_sift* s, const uint8_t* pixels, float* keypoints, float* orientations,
+                     float* descriptors, int capacity, int counts[MIF_SIFT_OCTAVES], float* elapsed_ms)
+{
+    if (!s || !pixels || !keypoints || !counts) {
+        mif::set_error("mif_sift_extract: NULL argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    if ((orientations == nullptr) != (descriptors == nullptr)) {
+        mif::set_error("mif_sift_extract: orientations and descriptors must both be given or both be NULL");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(s->device);
+    const int want_desc = descriptors ? 1 : 0;
+    for (int o = 0; o < kOctaves; o++) counts[o] = 0;
+    MIF_HIP(hipMemcpyAsync(s->d_pixels, pixels, (size_t)s->W * s->H * s->C, hipMemcpyHostToDevice, s->stream));
+    int rc = enqueue_frame(s, s->d_pixels, want_desc);
+    if (rc != MIF_OK) return rc;
+    rc = fetch_counts(s);
+    if (rc != MIF_OK) return rc;
+    if (elapsed_ms) MIF_HIP(hipEventElapsedTime(elapsed_ms, s->ev0, s->ev1));
+    if (s->h_counts[CNT_STATUS] != 0) {
+        mif::set_error("an octave produced no keypoints");
+        return s->h_counts[CNT_STATUS];
+    }
+    const int total = s->h_counts[CNT_TOTAL];
+    if (total > capacity) {
+        mif::set_error("mif_sift_extract: %d keypoints do not fit capacity %d", total, capacity);
+        return MIF_ERR_CAPACITY;
+    }
+    for (int o = 0; o < kOctaves; o++) counts[o] = s->h_counts[CNT_OCT0 + o];
+    if (total > 0) {
+        MIF_HIP(hipMemcpyAsync(keypoints, s->kp, (size_t)total * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+        if (want_desc) {
+            MIF_HIP(hipMemcpyAsync(orientations, s->orient, (size_t)total * sizeof(float), hipMemcpyDeviceToHost,
+                                   s->stream));
+            MIF_HIP(hipMemcpyAsync(descriptors, s->desc, (size_t)total * 128 * sizeof(float),
+                                   hipMemcpyDeviceToHost, s->stream));
+        }
+        MIF_HIP(hipStreamSynchronize(s->stream));
+    }
+    return MIF_OK;
+}
+
+int mif_sift_copy_level(mif_sift* s, int octave, int level, float* out)
+{
+    if (!s || !out || octave < 0 || octave >= kOctaves || level < 0 || level >= kLevels) {
+        mif::set_error("mif_sift_copy_level: bad argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(s->device);
+    const OctaveBuf& O = s->oct[octave];
+    const size_t items = (size_t)O.w * O.h;
+    MIF_HIP(hipStreamSynchronize(s->stream));
+    MIF_HIP(hipMemcpy(out, O.pyr + level * items, items * sizeof(float), hipMemcpyDeviceToHost));
+    return MIF_OK;
+}
+
+int mif_sift_copy_dog(mif_sift* s, int octave, int index, float* out)
+{
+    if (!s || !out || octave < 0 || octave >= kOctaves || index < 0 || index >= kLevels - 1) {
+        mif::set_error("mif_sift_copy_dog: bad argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(s->device);
+    const OctaveBuf& O = s->oct[octave];
+    const size_t items = (size_t)O.w * O.h;
+    MIF_HIP(hipStreamSynchronize(s->stream));
+    MIF_HIP(hipMemcpy(out, O.dog + index * items, items * sizeof(float), hipMemcpyDeviceToHost));
+    return MIF_OK;
+}
+
+int mif_sift_taps(const mif_sift* s, int level, float* out, int capacity)
+{
+    if (!s || level < 0 || level >= kLevels) return MIF_ERR_INVALID_ARGUMENT;
+    const int n = (int)s->taps[level].size();
+    for (int i = 0; i < n && i < capacity; i++) out[i] = s->taps[level][i];
+    return s->fr[level];
+}
+
+int mif_sift_last_elapsed_ms(mif_sift* s, float* ms)
+{
+    if (!s || !ms || !s->frame_done) return MIF_ERR_INVALID_ARGUMENT;
+    mif::DeviceGuard guard(s->device);
+    MIF_HIP(hipEventSynchronize(s->ev1));
+    MIF_HIP(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    return MIF_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,86 @@
+"""Host-side mirror of the reference's matching step (common/kpmatch.h) over the C ABI."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class Matcher:
+    """Exact brute-force L2 two-nearest-neighbour search on the GPU (replaces the FLANN
+    calls of common/kpmatch.h:174-176 and 284-286)."""
+
+    def __init__(self, max_query, max_database, device=0):
+        self._lib = _lib.load_library()
+        h = C.c_void_p()
+        _lib.check(self._lib.mif_match_create(device, max_query, max_database, C.byref(h)))
+        self._h = h
+        self.max_query, self.max_database, self.device = max_query, max_database, device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mif_match_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def top2(self, q, db, dim=None):
+        """q [nq, ld], db [nd, ld] float32 host arrays; only the first `dim` columns take part.
+        Returns idx [nq, 2] int32 (-1 = missing) and dist [nq, 2] float32 (inf = missing)."""
+        q = np.ascontiguousarray(q, np.float32)
+        db = np.ascontiguousarray(db, np.float32)
+        if q.ndim != 2 or db.ndim != 2 or (len(db) and q.shape[1] != db.shape[1]):
+            raise ValueError("q and db must be 2-d with the same row length")
+        ld = q.shape[1]
+        dim = ld if dim is None else dim
+        nq, nd = len(q), len(db)
+        idx = np.full((nq, 2), -1, np.int32)
+        dist = np.full((nq, 2), np.inf, np.float32)
+        if nq:
+            _lib.check(self._lib.mif_match_top2(self._h, q.ctypes.data, nq, db.ctypes.data if nd else None, nd,
+                                                dim, ld, idx.ctypes.data, dist.ctypes.data))
+        return idx, dist
+
+    def top2_device(self, d_q, nq, d_db, nd, dim, ld, d_idx2, d_dist2, d_nq=None, d_nd=None, stream=None):
+        """All pointers are integer device addresses; see mif_match_top2_device."""
+        _lib.check(self._lib.mif_match_top2_device(
+            self._h, C.c_void_p(d_q), nq, C.c_void_p(d_nq) if d_nq else None, C.c_void_p(d_db), nd,
+            C.c_void_p(d_nd) if d_nd else None, dim, ld, C.c_void_p(d_idx2), C.c_void_p(d_dist2),
+            C.c_void_p(stream) if stream else None))
+
+
+def pack_sift_rows(descriptors):
+    """Descriptor matrix as fmatches::ConvertToSift_feat + ConvertToCVKeyPoint build it
+    (common/kpmatch.h:15,127-128,141-142): sift_feat::descriptor starts with one zero
+    and the 128 values are appended, so matrix row = [0, d0 .. d126]."""
+    d = np.asarray(descriptors, np.float32).reshape(-1, 128)
+    out = np.zeros_like(d)
+    out[:, 1:] = d[:, :127]
+    return out
+
+
+def match_sift_features(matcher, desc_object, desc_scene):
+    """SIFT overload of Plot_Img_Matches_ocv up to the good-match list
+    (common/kpmatch.h:174-202): nearest neighbour of every object row, then keep
+    distance <= max(2.5 * min_dist, 0.35) with min_dist starting at 100.
+    Returns (matches [M,2] int32 {queryIdx, trainIdx}, distances [M], min_dist, max_dist)."""
+    q, db = pack_sift_rows(desc_object), pack_sift_rows(desc_scene)
+    idx, dist = matcher.top2(q, db)
+    d0 = dist[:, 0].astype(np.float64)
+    min_dist, max_dist = 100.0, 0.0
+    if len(d0):
+        min_dist = min(min_dist, float(d0.min()))
+        max_dist = max(max_dist, float(d0.max()))
+    keep = dist[:, 0] <= max(2.5 * min_dist, 0.35)
+    qi = np.nonzero(keep)[0].astype(np.int32)
+    return np.stack([qi, idx[keep, 0]], axis=1), dist[keep, 0], min_dist, max_dist
+
+
+def match_ratio_test(matcher, desc_object, desc_scene, ratio=0.75):
+    """SURF overload of Plot_Img_Matches_ocv up to the good-match list
+    (common/kpmatch.h:284-297): 2-NN, keep d0 < 0.75 * d1."""
+    idx, dist = matcher.top2(desc_object, desc_scene)
+    keep = dist[:, 0] < np.float32(ratio) * dist[:, 1]
+    qi = np.nonzero(keep)[0].astype(np.int32)
+    return np.stack([qi, idx[keep, 0]], axis=1), dist[keep, 0]

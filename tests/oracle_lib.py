@@ -1,0 +1,160 @@
+"""ctypes access to the CPU checker library built from oracle/ (test infrastructure only)."""
+import ctypes as C
+import os
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "build", "liboracle.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            raise RuntimeError("oracle library missing: run `make -C oracle` (or __graft_entry__.build())")
+        L = C.CDLL(ORACLE_SO)
+        L.orc_sift_create.restype = C.c_void_p
+        L.orc_sift_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.orc_sift_destroy.argtypes = [C.c_void_p]
+        L.orc_sift_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        for name in ("orc_sift_octave_width", "orc_sift_octave_height", "orc_sift_max_features",
+                     "orc_sift_count", "orc_sift_raw_count"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+            getattr(L, name).restype = C.c_int
+        for name in ("orc_sift_pyramid", "orc_sift_dog", "orc_sift_keypoints", "orc_sift_orientations",
+                     "orc_sift_descriptors"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int]
+            getattr(L, name).restype = C.POINTER(C.c_float)
+        L.orc_sift_taps.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.c_int]
+        L.orc_sift_taps.restype = C.c_int
+        for name in ("orc_math_expf", "orc_math_exp2f", "orc_math_sinf", "orc_math_cosf"):
+            getattr(L, name).argtypes = [C.c_float]
+            getattr(L, name).restype = C.c_float
+        L.orc_math_atan2f.argtypes = [C.c_float, C.c_float]
+        L.orc_math_atan2f.restype = C.c_float
+        L.orc_match_top2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_match_top2.restype = C.c_int
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_get_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def read_pnm(path):
+    """Binary PGM (P5) or PPM (P6) -> uint8 array [h, w] or [h, w, 3] (RGB order as stored)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    toks, pos = [], 0
+    while len(toks) < 4:
+        while data[pos:pos + 1].isspace():
+            pos += 1
+        if data[pos:pos + 1] == b"#":
+            while data[pos:pos + 1] != b"\n":
+                pos += 1
+            continue
+        start = pos
+        while not data[pos:pos + 1].isspace():
+            pos += 1
+        toks.append(data[start:pos])
+    pos += 1
+    magic, w, h, maxv = toks[0], int(toks[1]), int(toks[2]), int(toks[3])
+    assert maxv == 255
+    ch = {b"P5": 1, b"P6": 3}[magic]
+    arr = np.frombuffer(data, dtype=np.uint8, count=w * h * ch, offset=pos)
+    return arr.reshape(h, w) if ch == 1 else arr.reshape(h, w, 3)
+
+
+def _arr(ptr, n, dtype=np.float32):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+
+
+class SiftOracle:
+    """One CPU run of the restated reference pipeline, with every intermediate image exposed."""
+
+    def __init__(self, width, height, channels=1):
+        self.L = lib()
+        self.h = self.L.orc_sift_create(width, height, channels)
+        if not self.h:
+            raise ValueError("bad image geometry")
+        self.width, self.height, self.channels = width, height, channels
+
+    def close(self):
+        if self.h:
+            self.L.orc_sift_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def run(self, pixels, want_descriptors=True):
+        px = np.ascontiguousarray(pixels, dtype=np.uint8)
+        assert px.size == self.width * self.height * self.channels
+        return self.L.orc_sift_run(self.h, px.ctypes.data, 1 if want_descriptors else 0)
+
+    def dims(self, o):
+        return self.L.orc_sift_octave_width(self.h, o), self.L.orc_sift_octave_height(self.h, o)
+
+    def max_features(self, o):
+        return self.L.orc_sift_max_features(self.h, o)
+
+    def count(self, o):
+        return self.L.orc_sift_count(self.h, o)
+
+    def raw_count(self, o):
+        return self.L.orc_sift_raw_count(self.h, o)
+
+    def pyramid(self, o):
+        w, h = self.dims(o)
+        return _arr(self.L.orc_sift_pyramid(self.h, o), 6 * w * h).reshape(6, h, w)
+
+    def dog(self, o):
+        w, h = self.dims(o)
+        return _arr(self.L.orc_sift_dog(self.h, o), 5 * w * h).reshape(5, h, w)
+
+    def keypoints(self, o):
+        n = self.count(o)
+        return _arr(self.L.orc_sift_keypoints(self.h, o), 4 * n).reshape(n, 4)
+
+    def orientations(self, o):
+        n = self.count(o)
+        return _arr(self.L.orc_sift_orientations(self.h, o), n)
+
+    def descriptors(self, o):
+        n = self.count(o)
+        return _arr(self.L.orc_sift_descriptors(self.h, o), 128 * n).reshape(n, 128)
+
+    def taps(self, level):
+        buf = (C.c_float * 64)()
+        fr = self.L.orc_sift_taps(self.h, level, buf, 64)
+        return np.array(buf[:2 * fr + 1], dtype=np.float32), fr
+
+    def all_features(self):
+        """Octave-major concatenation, as the reference returns it (sift.cpp:1889-1911)."""
+        kps, ors, des, octs = [], [], [], []
+        for o in range(3):
+            n = self.count(o)
+            kps.append(self.keypoints(o))
+            octs.append(np.full(n, o, dtype=np.int32))
+            ors.append(self.orientations(o) if n else np.zeros(0, np.float32))
+            des.append(self.descriptors(o) if n else np.zeros((0, 128), np.float32))
+        return np.concatenate(kps), np.concatenate(octs), np.concatenate(ors), np.concatenate(des)
+
+
+def match_top2(q, db, dim=None):
+    """CPU statement of mif_match_top2 (same contract)."""
+    q = np.ascontiguousarray(q, np.float32)
+    db = np.ascontiguousarray(db, np.float32)
+    ld = q.shape[1]
+    dim = ld if dim is None else dim
+    nq, nd = len(q), len(db)
+    idx = np.full((nq, 2), -1, np.int32)
+    dist = np.full((nq, 2), np.inf, np.float32)
+    if nq:
+        lib().orc_match_top2(q.ctypes.data, nq, db.ctypes.data if nd else None, nd, dim, ld,
+                             idx.ctypes.data, dist.ctypes.data)
+    return idx, dist

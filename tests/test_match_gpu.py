@@ -1,0 +1,95 @@
+"""GPU parity of the MFMA matcher (through the C ABI) against the CPU checker: indices exact,
+distances bit-identical."""
+import numpy as np
+import pytest
+
+import object_detection_amd as oda
+import oracle_lib as orc
+from synth import sift_like_descriptors
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(q, db, dim=None, matcher=None):
+    m = matcher or oda.Matcher(max(len(q), 1), max(len(db), 1))
+    idx_g, dist_g = m.top2(q, db, dim)
+    idx_o, dist_o = orc.match_top2(q, db, dim)
+    assert np.array_equal(idx_g, idx_o)
+    assert np.array_equal(dist_g.view(np.uint32), dist_o.view(np.uint32))
+    return idx_g, dist_g
+
+
+@pytest.mark.parametrize("nq,nd", [(1, 1), (1, 2), (37, 211), (128, 32), (129, 33), (300, 5000), (1000, 1000)])
+def test_top2_parity_sizes(nq, nd):
+    q = sift_like_descriptors(nq, seed=nq)
+    db = sift_like_descriptors(nd, seed=10_000 + nd)
+    _check(q, db)
+
+
+def test_ties_duplicates_and_missing():
+    q = sift_like_descriptors(70, 1)
+    db = sift_like_descriptors(400, 2)
+    db[17] = q[3]
+    db[40] = db[90] = db[333] = q[5]
+    db[100:140] = db[100]                      # 40 identical rows
+    q[9] = db[100]
+    idx, dist = _check(q, db)
+    assert idx[3, 0] == 17 and dist[3, 0] == 0
+    assert list(idx[5]) == [40, 90]
+    assert list(idx[9]) == [100, 101]
+    idx, dist = _check(q, db[:1])
+    assert np.all(idx[:, 1] == -1) and np.all(np.isinf(dist[:, 1]))
+    idx, dist = _check(q, db[:0])
+    assert np.all(idx == -1)
+
+
+def test_shifted_rows_dim127_and_surf_dim64():
+    a = sift_like_descriptors(150, 3)
+    b = sift_like_descriptors(170, 4)
+    qa, qb = oda.pack_sift_rows(a), oda.pack_sift_rows(b)
+    i1, d1 = _check(qa, qb)
+    i2, d2 = _check(a, b, dim=127)            # same rows without the shift: identical answer
+    assert np.array_equal(i1, i2) and np.array_equal(d1, d2)
+    rng = np.random.RandomState(5)
+    s1 = rng.standard_normal((90, 64)).astype(np.float32)
+    s2 = rng.standard_normal((260, 64)).astype(np.float32)
+    s1 /= np.linalg.norm(s1, axis=1, keepdims=True)
+    s2 /= np.linalg.norm(s2, axis=1, keepdims=True)
+    _check(s1, s2)
+
+
+def test_good_match_filters():
+    a = sift_like_descriptors(200, 6)
+    b = sift_like_descriptors(300, 7)
+    rng = np.random.RandomState(8)
+    b[:120] = np.clip(a[:120] + rng.normal(0, 4, (120, 128)), 0, 255).astype(np.float32)
+    m = oda.Matcher(200, 300)
+    matches, dist, mn, mx = oda.match_sift_features(m, a, b)
+    idx_o, dist_o = orc.match_top2(oda.pack_sift_rows(a), oda.pack_sift_rows(b))
+    thr = max(2.5 * min(100.0, float(dist_o[:, 0].min())), 0.35)
+    keep = dist_o[:, 0] <= thr
+    assert np.array_equal(matches[:, 0], np.nonzero(keep)[0])
+    assert np.array_equal(matches[:, 1], idx_o[keep, 0])
+    assert len(matches) >= 100
+    good, _ = oda.match_ratio_test(m, a, b)
+    keep = dist_o_full = None
+    idx_f, dist_f = orc.match_top2(a, b)
+    keep = dist_f[:, 0] < np.float32(0.75) * dist_f[:, 1]
+    assert np.array_equal(good[:, 0], np.nonzero(keep)[0]) and np.array_equal(good[:, 1], idx_f[keep, 0])
+
+
+def test_large_parity_subset_and_property():
+    """4096 x 65536 x 128 against the checker, then a 16384 x 131072 planted-neighbour property run."""
+    db = sift_like_descriptors(65536, 11)
+    rng = np.random.RandomState(12)
+    perm = rng.permutation(65536)[:4096]
+    q = np.clip(db[perm] + rng.normal(0, 8, (4096, 128)), 0, 255).astype(np.float32)
+    m = oda.Matcher(16384, 131072)
+    idx, dist = _check(q, db, matcher=m)
+    assert (idx[:, 0] == perm).mean() > 0.99
+    db2 = sift_like_descriptors(131072, 13)
+    perm2 = rng.permutation(131072)[:16384]
+    q2 = db2[perm2].copy()
+    idx2, dist2 = m.top2(q2, db2)
+    assert np.array_equal(idx2[:, 0], perm2.astype(np.int32))      # exact copies come back with distance 0
+    assert np.all(dist2[:, 0] == 0) and np.all(dist2[:, 1] > 0)

@@ -1,0 +1,194 @@
+"""CPU tests of the checker itself: shared math, filter taps, and the restated
+pipeline against (a) an independent numpy float64 restatement of the linear
+stages and (b) the committed golden tables."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as orc
+from synth import blob_image, sift_like_descriptors
+
+
+def _ulp_err(got, want):
+    got = np.asarray(got, np.float64)
+    want = np.asarray(want, np.float64)
+    ulp = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64)
+    return np.abs(got - want) / ulp
+
+
+def test_shared_math_accuracy():
+    L = orc.lib()
+    rng = np.random.RandomState(1)
+    xs = np.concatenate([rng.uniform(-80, 0, 4000), rng.uniform(0, 10, 1000)]).astype(np.float32)
+    err = _ulp_err([L.orc_math_expf(float(x)) for x in xs], np.exp(xs.astype(np.float64)))
+    assert err.max() <= 2.0
+    xs = rng.uniform(-3, 3, 4000).astype(np.float32)
+    err = _ulp_err([L.orc_math_exp2f(float(x)) for x in xs], np.exp2(xs.astype(np.float64)))
+    assert err.max() <= 2.0
+    a = rng.uniform(-1, 1, (6000, 2)).astype(np.float32)
+    got = np.array([L.orc_math_atan2f(float(y), float(x)) for y, x in a])
+    want = np.arctan2(a[:, 0].astype(np.float64), a[:, 1].astype(np.float64))
+    assert np.abs(got - want).max() <= 5e-7
+    assert L.orc_math_atan2f(0.0, 0.0) == 0.0
+    assert abs(L.orc_math_atan2f(0.0, -1.0) - math.pi) < 1e-6
+    xs = rng.uniform(-7, 7, 6000).astype(np.float32)
+    s = np.array([L.orc_math_sinf(float(x)) for x in xs])
+    c = np.array([L.orc_math_cosf(float(x)) for x in xs])
+    assert np.abs(s - np.sin(xs.astype(np.float64))).max() <= 3e-7
+    assert np.abs(c - np.cos(xs.astype(np.float64))).max() <= 3e-7
+
+
+def test_taps_match_reference_radii():
+    S = orc.SiftOracle(64, 48)
+    radii = []
+    for l in range(6):
+        t, fr = S.taps(l)
+        radii.append(fr)
+        assert len(t) == 2 * fr + 1
+        assert abs(float(t.sum()) - 1.0) < 1e-6
+        assert np.array_equal(t, t[::-1])
+    # widths 13, 11, 13, 15, 19, 23 for sigma0 = 1.6, k = 2^(1/3) (sift.cpp:819-889)
+    assert radii == [6, 5, 6, 7, 9, 11]
+
+
+def _np_blur(img, taps, fr):
+    """float64 restatement of kBlurH + kBlurV including the dropped last tap."""
+    h, w = img.shape
+    pad = np.zeros((h, w + 2 * fr), np.float64)
+    pad[:, fr:fr + w] = img
+    tmp = np.zeros((h, w), np.float64)
+    for i in range(-fr, fr):
+        tmp += float(taps[fr + i]) * pad[:, fr + i:fr + i + w]
+    tmp = tmp.astype(np.float32).astype(np.float64)
+    pad = np.zeros((h + 2 * fr, w), np.float64)
+    pad[fr:fr + h] = tmp
+    out = np.zeros((h, w), np.float64)
+    for i in range(-fr, fr):
+        out += float(taps[fr + i]) * pad[fr + i:fr + i + h]
+    return out
+
+
+@pytest.mark.parametrize("size", [(64, 48), (97, 61)])
+def test_scale_space_against_numpy(size):
+    w, h = size
+    img = blob_image(w, h, seed=3)
+    S = orc.SiftOracle(w, h)
+    assert S.run(img, want_descriptors=False) == 0
+    p = S.pyramid(0)
+    cur = img.astype(np.float32) / np.float32(255.0)
+    for l in range(6):
+        t, fr = S.taps(l)
+        want = _np_blur(cur.astype(np.float64), t, fr)
+        assert np.abs(p[l] - want).max() < 2e-6
+        cur = p[l]
+    d = S.dog(0)
+    for i in range(5):
+        assert np.array_equal(d[i], p[i + 1] - p[i])
+    # octave 1 base = level 3 of octave 0 sampled with the reference's indexing (sift.cpp:128-129)
+    w1, h1 = S.dims(1)
+    flat = p.reshape(-1)
+    yy, xx = np.mgrid[0:h1, 0:w1]
+    base1 = flat[(yy * 2) * (2 * w1) + xx * 2 + 3 * (2 * w1) * (2 * h1)]
+    t, fr = S.taps(0)
+    want = _np_blur(base1.astype(np.float64), t, fr)
+    assert np.abs(S.pyramid(1)[0] - want).max() < 2e-6
+
+
+def test_octave_geometry_and_limits():
+    S = orc.SiftOracle(324, 223)
+    assert [S.dims(o) for o in range(3)] == [(324, 223), (162, 111), (81, 55)]
+    assert [S.max_features(o) for o in range(3)] == [722, 179, 44]
+
+
+def test_flat_image_returns_minus_one():
+    S = orc.SiftOracle(64, 64)
+    assert S.run(np.full((64, 64), 128, np.uint8)) == -1
+    assert S.count(0) == 0
+
+
+def test_list_limit():
+    from synth import dense_image
+    S = orc.SiftOracle(256, 192)
+    assert S.run(dense_image(256, 192, 0)) == 0
+    assert S.raw_count(0) > S.max_features(0)
+    assert S.count(0) == S.max_features(0)
+    assert len(S.descriptors(0)) == S.max_features(0)
+
+
+def test_keypoint_invariants():
+    img = blob_image(256, 192, seed=1)
+    S = orc.SiftOracle(256, 192)
+    assert S.run(img) == 0
+    for o in range(3):
+        kp = S.keypoints(o)
+        w, h = S.dims(o)
+        assert len(kp) <= S.max_features(o)
+        if not len(kp):
+            continue
+        assert np.all(np.isin(kp[:, 3], [1, 2, 3]))
+        sc = 2.0 ** o
+        assert np.all(kp[:, 0] / sc > 4) and np.all(kp[:, 0] / sc < w - 4)
+        assert np.all(kp[:, 1] / sc > 4) and np.all(kp[:, 1] / sc < h - 4)
+        ori = S.orientations(o)
+        assert np.all((ori == -1) | ((ori >= -math.pi - 1e-6) & (ori <= math.pi + 1e-6)))
+        d = S.descriptors(o)
+        assert np.all(d >= 0) and np.all(d <= 255)
+
+
+def test_color_path_close_to_gray():
+    g = blob_image(96, 80, seed=5)
+    bgr = np.repeat(g[:, :, None], 3, axis=2)
+    A = orc.SiftOracle(96, 80, 1)
+    B = orc.SiftOracle(96, 80, 3)
+    assert A.run(g, False) == 0 and B.run(bgr, False) == 0
+    assert np.abs(A.pyramid(0) - B.pyramid(0)).max() < 1e-6
+
+
+GOLD = os.path.join(orc.GOLDEN, "sift_golden.npz")
+
+
+@pytest.mark.parametrize("name", ["box", "scene", "blob_256x192", "blob_bgr_200x150", "dense_256x192", "blob_bgr_97x61"])
+def test_oracle_matches_golden_tables(name):
+    from make_golden import load_case
+    gold = np.load(GOLD)
+    img = load_case(name)
+    h, w = img.shape[:2]
+    S = orc.SiftOracle(w, h, 1 if img.ndim == 2 else 3)
+    rc = S.run(img)
+    assert rc == int(gold[name + "_rc"])
+    if rc != 0:
+        return
+    kp, octs, ori, des = S.all_features()
+    assert np.array_equal(kp, gold[name + "_kp"])
+    assert np.array_equal(octs, gold[name + "_oct"])
+    assert np.array_equal(ori, gold[name + "_ori"])
+    assert np.array_equal(des, gold[name + "_des"])
+    for o in range(3):
+        assert np.array_equal(S.dog(o).view(np.uint32).sum(dtype=np.uint64), gold["%s_dogsum%d" % (name, o)])
+
+
+def test_match_oracle_against_numpy():
+    q = sift_like_descriptors(37, 1)
+    db = sift_like_descriptors(211, 2)
+    db[17] = q[3]
+    db[40] = db[90] = q[5]                 # exact tie -> lowest index first
+    idx, dist = orc.match_top2(q, db)
+    d = np.sqrt(((q[:, None, :].astype(np.float64) - db[None].astype(np.float64)) ** 2).sum(-1))
+    order = np.argsort(d, axis=1, kind="stable")[:, :2]
+    assert np.array_equal(idx, order.astype(np.int32))
+    assert np.allclose(dist, np.take_along_axis(d, order, 1), rtol=1e-6, atol=1e-4)
+    assert idx[3, 0] == 17 and dist[3, 0] == 0.0
+    assert list(idx[5]) == [40, 90]
+    # dim < ld: trailing columns ignored
+    q2, db2 = q.copy(), db.copy()
+    q2[:, 127] = 1e6
+    idx2, _ = orc.match_top2(q2, db2, dim=127)
+    idx3, _ = orc.match_top2(q[:, :127].copy(), db[:, :127].copy())
+    assert np.array_equal(idx2, idx3)
+    # degenerate databases
+    idx, dist = orc.match_top2(q, db[:1])
+    assert np.all(idx[:, 0] == 0) and np.all(idx[:, 1] == -1) and np.all(np.isinf(dist[:, 1]))
+    idx, dist = orc.match_top2(q, db[:0])
+    assert np.all(idx == -1) and np.all(np.isinf(dist))

@@ -1,0 +1,150 @@
+"""GPU parity: the HIP SIFT path (through the C ABI) against the CPU checker and the golden tables.
+
+Bar: counts, levels, octave ids exact; every fp32 output bit-identical (the two
+sides execute the same IEEE operation sequence); should a platform ever differ in
+an fp32 bit, the documented tolerances are x, y, sigma 1e-3, orientation 1e-3 rad,
+descriptor 0.5 of 0..255 -- the asserts below demand equality."""
+import os
+
+import numpy as np
+import pytest
+
+import object_detection_amd as oda
+import oracle_lib as orc
+from make_golden import CASES, load_case
+from synth import blob_image, dense_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_pair(img):
+    h, w = img.shape[:2]
+    c = 1 if img.ndim == 2 else 3
+    S = orc.SiftOracle(w, h, c)
+    rc_o = S.run(img)
+    ex = oda.SiftExtractor(w, h, c)
+    rc_g, f = ex.extract(img)
+    return S, rc_o, ex, rc_g, f
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_scale_space_bit_exact(name):
+    img = load_case(name)
+    h, w = img.shape[:2]
+    c = 1 if img.ndim == 2 else 3
+    S = orc.SiftOracle(w, h, c)
+    S.run(img, want_descriptors=False)
+    ex = oda.SiftExtractor(w, h, c)
+    ex.extract(img, want_descriptors=False)
+    for l in range(6):
+        t_o, fr_o = S.taps(l)
+        t_g, fr_g = ex.taps(l)
+        assert fr_o == fr_g and np.array_equal(t_o, t_g)
+    for o in range(3):
+        assert ex.octave_info(o) == (*S.dims(o), S.max_features(o))
+        p = S.pyramid(o)
+        d = S.dog(o)
+        for l in range(6):
+            assert np.array_equal(ex.level(o, l).view(np.uint32), p[l].view(np.uint32)), (o, l)
+        for i in range(5):
+            assert np.array_equal(ex.dog(o, i).view(np.uint32), d[i].view(np.uint32)), (o, i)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_features_match_checker_and_golden(name):
+    img = load_case(name)
+    S, rc_o, ex, rc_g, f = _run_pair(img)
+    gold = np.load(os.path.join(orc.GOLDEN, "sift_golden.npz"))
+    assert rc_g == rc_o == int(gold[name + "_rc"])
+    if rc_o != 0:
+        assert f.counts == [0, 0, 0] and len(f.keypoints) == 0
+        return
+    kp, octs, ori, des = S.all_features()
+    assert f.counts == [S.count(o) for o in range(3)]
+    assert np.array_equal(f.octave_ids, octs)
+    assert np.array_equal(f.keypoints.view(np.uint32), kp.view(np.uint32))
+    assert np.array_equal(f.orientations.view(np.uint32), ori.view(np.uint32))
+    assert np.array_equal(f.descriptors.view(np.uint32), des.view(np.uint32))
+    assert np.array_equal(f.keypoints, gold[name + "_kp"])
+    assert np.array_equal(f.descriptors, gold[name + "_des"])
+
+
+def test_detector_only_and_list_limit():
+    img = dense_image(256, 192, 0)
+    S = orc.SiftOracle(256, 192)
+    S.run(img, want_descriptors=False)
+    ex = oda.SiftExtractor(256, 192)
+    rc, f = ex.extract(img, want_descriptors=False)
+    assert rc == 0
+    status, counts, raw = ex.read_counts()
+    assert counts == [S.count(o) for o in range(3)]
+    assert raw == [S.raw_count(o) for o in range(3)]
+    assert raw[0] > ex.octave_info(0)[2] == counts[0]
+    kp = np.concatenate([S.keypoints(o) for o in range(3)])
+    assert np.array_equal(f.keypoints.view(np.uint32), kp.view(np.uint32))
+
+
+def test_flat_image_and_handle_reuse():
+    ex = oda.SiftExtractor(256, 192)
+    rc, f = ex.extract(np.full((192, 256), 77, np.uint8))
+    assert rc == -1 and f.counts == [0, 0, 0]
+    # the same handle then processes a normal frame correctly (no state leaks between frames)
+    img = blob_image(256, 192, seed=1)
+    S = orc.SiftOracle(256, 192)
+    assert S.run(img) == 0
+    rc, f = ex.extract(img)
+    assert rc == 0
+    assert np.array_equal(f.descriptors.view(np.uint32), S.all_features()[3].view(np.uint32))
+    rc2, f2 = ex.extract(img)
+    assert np.array_equal(f.keypoints, f2.keypoints) and np.array_equal(f.descriptors, f2.descriptors)
+
+
+@pytest.mark.parametrize("size", [(64, 64), (65, 47), (333, 129), (1, 1), (12, 300)])
+def test_ragged_sizes_scale_space(size):
+    w, h = size
+    img = blob_image(w, h, seed=w * 1000 + h)
+    S = orc.SiftOracle(w, h)
+    rc_o = S.run(img, want_descriptors=False)
+    ex = oda.SiftExtractor(w, h)
+    rc_g, f = ex.extract(img, want_descriptors=False)
+    assert rc_g == rc_o == 0
+    for o in range(3):
+        ow, oh = S.dims(o)
+        if ow * oh == 0:
+            continue
+        for i in range(5):
+            assert np.array_equal(ex.dog(o, i).view(np.uint32), S.dog(o)[i].view(np.uint32)), (o, i)
+    kp = np.concatenate([S.keypoints(o) for o in range(3)])
+    assert np.array_equal(f.keypoints.view(np.uint32), kp.view(np.uint32))
+
+
+def test_module_level_extract_features_tracks_size_changes():
+    a = load_case("box")
+    b = load_case("scene")
+    for img in (a, b, a):
+        rc, f = oda.extract_features(img, offload=0.0)
+        h, w = img.shape
+        S = orc.SiftOracle(w, h)
+        assert S.run(img) == rc == 0
+        assert np.array_equal(f.descriptors.view(np.uint32), S.all_features()[3].view(np.uint32))
+
+
+def test_full_hd_properties_and_parity():
+    """1080p BGR frame (the benchmark workload): parity with the checker plus
+    size-independent properties: determinism and list limits."""
+    img = blob_image(1920, 1080, seed=1234, channels=3)
+    ex = oda.SiftExtractor(1920, 1080, 3)
+    rc, f = ex.extract(img)
+    assert rc == 0
+    rc2, f2 = ex.extract(img)
+    assert np.array_equal(f.keypoints, f2.keypoints) and np.array_equal(f.descriptors, f2.descriptors)
+    for o in range(3):
+        assert f.counts[o] <= ex.octave_info(o)[2]
+    assert np.all((f.descriptors >= 0) & (f.descriptors <= 255))
+    S = orc.SiftOracle(1920, 1080, 3)
+    assert S.run(img) == 0
+    kp, octs, ori, des = S.all_features()
+    assert f.counts == [S.count(o) for o in range(3)]
+    assert np.array_equal(f.keypoints.view(np.uint32), kp.view(np.uint32))
+    assert np.array_equal(f.orientations.view(np.uint32), ori.view(np.uint32))
+    assert np.array_equal(f.descriptors.view(np.uint32), des.view(np.uint32))
