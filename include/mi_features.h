@@ -34,6 +34,10 @@ extern "C" {
 #define MIF_SIFT_OCTAVES 3   /* _SIFT_MAX_OCTAVES, SIFT/sift.cpp:24 */
 #define MIF_SIFT_LEVELS 6    /* _SIFT_INTVLS + 3,  SIFT/sift.cpp:17,23 */
 #define MIF_SIFT_DESC_DIM 128
+/* Timed stages of an octave: 0 base image (gray conversion or decimation),
+ * 1 scale space (the six blur + DoG launches), 2 detector (detect, scan, emit),
+ * 3 orientation + descriptor. */
+#define MIF_SIFT_STAGES 4
 
 const char* mif_last_error(void);
 int mif_device_count(void);
@@ -47,6 +51,12 @@ typedef struct mif_sift mif_sift;
  * plan for a width x height image with `channels` = 1 (gray) or 3 (interleaved
  * BGR) on GPU `device`. up_scale must be 0. */
 int mif_sift_create(int device, int width, int height, int channels, int up_scale, mif_sift** out);
+/* Same, with room for `batch` frames per enqueue: every kernel launch then
+ * covers the whole batch (frames are independent, as successive calls of the
+ * reference are). mif_sift_create is batch = 1. */
+int mif_sift_create_batched(int device, int width, int height, int channels, int up_scale, int batch,
+                            mif_sift** out);
+int mif_sift_batch(const mif_sift* s);
 int mif_sift_destroy(mif_sift* s);
 
 /* Geometry of octave o: size_t(w / 2^o), size_t(h / 2^o), max_features =
@@ -69,32 +79,52 @@ int mif_sift_capacity(const mif_sift* s);
 int mif_sift_extract(mif_sift* s, const uint8_t* pixels, float* keypoints, float* orientations,
                      float* descriptors, int capacity, int counts[MIF_SIFT_OCTAVES], float* elapsed_ms);
 
-/* Device-resident form of the same call: d_pixels already lives in HBM, the
- * frame is enqueued on the handle's stream and nothing is copied back.
- * want_descriptors = 0 stops after the detector (first overload of sift.h). */
-int mif_sift_enqueue(mif_sift* s, const void* d_pixels, int want_descriptors);
+/* Device-resident form of the same call: d_pixels holds nframes (<= batch)
+ * frames back to back in HBM; they are enqueued on the handle's stream and
+ * nothing is copied back. want_descriptors = 0 stops after the detector (first
+ * overload of sift.h). */
+int mif_sift_enqueue(mif_sift* s, const void* d_pixels, int nframes, int want_descriptors);
 /* Blocks until everything enqueued on the handle has finished. */
 int mif_sift_sync(mif_sift* s);
-/* Device addresses of the last frame's results, valid until the next enqueue:
- * keypoints float4[capacity], orientations float[capacity], descriptors
- * float[capacity][128], counts int32[8] = {n_oct0, n_oct1, n_oct2, n_total,
- * raw_oct0, raw_oct1, raw_oct2, status}. Any out pointer may be NULL. */
+/* Makes everything enqueued on s from now on wait for what has been enqueued
+ * on `other` so far (an event dependency between the two handles' streams; no
+ * host wait). Used when one handle's results feed work ordered on another. */
+int mif_sift_wait_for(mif_sift* s, mif_sift* other);
+/* Device addresses of the last batch's results, valid until the next enqueue.
+ * Frame f of the batch starts at row f * capacity of keypoints
+ * float4[batch][capacity], orientations float[batch][capacity], descriptors
+ * float[batch][capacity][128] and at counts + 8 f of counts int32[batch][8] =
+ * {n_oct0, n_oct1, n_oct2, n_total, raw_oct0, raw_oct1, raw_oct2, status}.
+ * Any out pointer may be NULL. */
 int mif_sift_device_results(mif_sift* s, void** d_keypoints, void** d_orientations, void** d_descriptors,
                             void** d_counts);
 /* The handle's hipStream_t, for callers that order their own work after a frame. */
 void* mif_sift_stream(mif_sift* s);
-/* Waits for the stream and reads the per-octave counts (clamped to
- * max_features) and raw detector totals. Either array may be NULL. */
-int mif_sift_read_counts(mif_sift* s, int counts[MIF_SIFT_OCTAVES], int raw_counts[MIF_SIFT_OCTAVES]);
+/* Waits for the stream and reads frame `frame`'s per-octave counts (clamped to
+ * max_features) and raw detector totals. Either array may be NULL. Returns the
+ * frame's status (0 or MIF_ERR_NO_KEYPOINTS). */
+int mif_sift_read_counts(mif_sift* s, int frame, int counts[MIF_SIFT_OCTAVES], int raw_counts[MIF_SIFT_OCTAVES]);
+/* Waits for the stream and copies one frame of the last batch to host buffers
+ * laid out as for mif_sift_extract (orientations / descriptors may be NULL).
+ * Returns the frame's status. */
+int mif_sift_copy_results(mif_sift* s, int frame, float* keypoints, float* orientations, float* descriptors,
+                          int capacity, int counts[MIF_SIFT_OCTAVES]);
 
 /* Replace the _DEBUG probes SIFT::get_blur / get_diff_blur (SIFT/sift.h:13-21):
- * copy one image of the last frame's scale space to the host.
- * level 0..5 of the Gaussian pyramid, index 0..4 of the DoG stack. */
-int mif_sift_copy_level(mif_sift* s, int octave, int level, float* out);
-int mif_sift_copy_dog(mif_sift* s, int octave, int index, float* out);
+ * copy one image of the scale space of frame `frame` of the last batch to the
+ * host. level 0..5 of the Gaussian pyramid, index 0..4 of the DoG stack. */
+int mif_sift_copy_level(mif_sift* s, int frame, int octave, int level, float* out);
+int mif_sift_copy_dog(mif_sift* s, int frame, int octave, int index, float* out);
 /* Gaussian taps of a level as the blur kernels use them (2*radius+1 floats;
  * Build_separable_filter_cof, SIFT/sift.cpp:819-889). Returns the radius. */
 int mif_sift_taps(const mif_sift* s, int level, float* out, int capacity);
+/* Per-stage GPU timing, the counterpart of the reference's per-task profile
+ * dump (SIFT::store_task_exec_times, SIFT/sift.h:71, SIFT/sift.cpp:1674-1703).
+ * While enabled, every enqueue records hipEvents on the handle's stream at the
+ * stage boundaries of each octave; mif_sift_stage_times waits for the stream and
+ * returns the last batch's milliseconds per [octave][stage]. */
+int mif_sift_set_timing(mif_sift* s, int enable);
+int mif_sift_stage_times(mif_sift* s, float ms[MIF_SIFT_OCTAVES][MIF_SIFT_STAGES]);
 /* GPU time of the last synchronised frame in ms (hipEvent pair). */
 int mif_sift_last_elapsed_ms(mif_sift* s, float* ms);
 
@@ -104,6 +134,8 @@ typedef struct mif_matcher mif_matcher;
 
 /* Workspace for matching up to max_query x max_database descriptors on `device`. */
 int mif_match_create(int device, int max_query, int max_database, mif_matcher** out);
+/* Same, for up to max_pairs independent (query set, database) pairs per call. */
+int mif_match_create_batched(int device, int max_query, int max_database, int max_pairs, mif_matcher** out);
 int mif_match_destroy(mif_matcher* m);
 
 /* Exact brute-force 2-nearest-neighbour search in L2; replaces the
@@ -122,6 +154,35 @@ int mif_match_top2(mif_matcher* m, const float* q, int nq, const float* db, int 
 int mif_match_top2_device(mif_matcher* m, const float* d_q, int nq, const int32_t* d_nq, const float* d_db,
                           int nd, const int32_t* d_nd, int dim, int ld, int32_t* d_idx2, float* d_dist2,
                           void* stream);
+
+
+/* One (query set, database) pair of a batched match; every pointer is a device
+ * address. d_nq / d_nd may be NULL (the call's nq / nd are then the row counts).
+ * d_good / d_summary / d_minmax are only written when a filter is requested and
+ * may otherwise be NULL. */
+typedef struct mif_match_pair {
+    const float* d_q;
+    const float* d_db;
+    const int32_t* d_nq;
+    const int32_t* d_nd;
+    int32_t* d_idx2;     /* [nq][2] */
+    float* d_dist2;      /* [nq][2] */
+    uint8_t* d_good;     /* [nq] 1 = kept by the filter */
+    int32_t* d_summary;  /* {kept, query rows} */
+    float* d_minmax;     /* {min_dist, max_dist} of the nearest distances (filter 1) */
+} mif_match_pair;
+
+#define MIF_FILTER_NONE 0
+/* Good-match rule of the SIFT overload of Plot_Img_Matches_ocv
+ * (common/kpmatch.h:177-202): keep dist <= max(2.5 * min_dist, 0.35). */
+#define MIF_FILTER_SIFT 1
+/* Lowe ratio test of the SURF overload (common/kpmatch.h:289-297): keep d0 < 0.75 * d1. */
+#define MIF_FILTER_RATIO 2
+
+/* npairs independent top-2 searches in one set of launches on `stream`; all
+ * pairs share the capacities nq / nd, dim and ld. `pairs` is a host array. */
+int mif_match_top2_batch_device(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq, int nd, int dim,
+                                int ld, int filter_mode, void* stream);
 
 #ifdef __cplusplus
 }

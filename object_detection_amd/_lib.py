@@ -20,24 +20,41 @@ SYMBOLS = [
     ("mif_last_error", C.c_char_p, []),
     ("mif_device_count", C.c_int, []),
     ("mif_sift_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("mif_sift_create_batched", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("mif_sift_batch", C.c_int, [_P]),
     ("mif_sift_destroy", C.c_int, [_P]),
     ("mif_sift_octave_info", C.c_int, [_P, C.c_int, _PI, _PI, _PI]),
     ("mif_sift_capacity", C.c_int, [_P]),
     ("mif_sift_extract", C.c_int, [_P, _P, _P, _P, _P, C.c_int, _PI, _PF]),
-    ("mif_sift_enqueue", C.c_int, [_P, _P, C.c_int]),
+    ("mif_sift_enqueue", C.c_int, [_P, _P, C.c_int, C.c_int]),
+    ("mif_sift_wait_for", C.c_int, [_P, _P]),
+    ("mif_sift_copy_results", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _PI]),
     ("mif_sift_sync", C.c_int, [_P]),
     ("mif_sift_device_results", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("mif_sift_stream", _P, [_P]),
-    ("mif_sift_read_counts", C.c_int, [_P, _PI, _PI]),
-    ("mif_sift_copy_level", C.c_int, [_P, C.c_int, C.c_int, _P]),
-    ("mif_sift_copy_dog", C.c_int, [_P, C.c_int, C.c_int, _P]),
+    ("mif_sift_read_counts", C.c_int, [_P, C.c_int, _PI, _PI]),
+    ("mif_sift_copy_level", C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    ("mif_sift_copy_dog", C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     ("mif_sift_taps", C.c_int, [_P, C.c_int, _PF, C.c_int]),
+    ("mif_sift_set_timing", C.c_int, [_P, C.c_int]),
+    ("mif_sift_stage_times", C.c_int, [_P, _P]),
     ("mif_sift_last_elapsed_ms", C.c_int, [_P, _PF]),
     ("mif_match_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("mif_match_create_batched", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("mif_match_destroy", C.c_int, [_P]),
+    ("mif_match_top2_batch_device", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("mif_match_top2", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     ("mif_match_top2_device", C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P]),
 ]
+
+
+class MatchPair(C.Structure):
+    """mif_match_pair of include/mi_features.h."""
+    _fields_ = [("d_q", _P), ("d_db", _P), ("d_nq", _P), ("d_nd", _P), ("d_idx2", _P), ("d_dist2", _P),
+                ("d_good", _P), ("d_summary", _P), ("d_minmax", _P)]
+
+
+FILTER_NONE, FILTER_SIFT, FILTER_RATIO = 0, 1, 2
 
 
 class MifError(RuntimeError):

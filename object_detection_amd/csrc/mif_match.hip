@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cmath>
+#include <cstring>
 #include "mif_common.h"
 
 namespace {
@@ -24,10 +25,19 @@ constexpr int kQT = 32;      // query rows per wave (one 32x32 MFMA tile)
 constexpr int kWaves = 4;    // waves per block, each with its own query tile
 constexpr int kDC = 32;      // database rows per staged chunk
 constexpr float kInf = __builtin_inff();
+constexpr int kMaxPairs = 32;   // pairs per launch (the table travels as a kernel argument)
 
-__global__ void k_row_norms(const float* __restrict__ m, int n_cap, const int* __restrict__ d_n, int dim, int ld,
-                            float* __restrict__ out)
+struct PairTable {
+    mif_match_pair p[kMaxPairs];
+};
+
+// grid (ceil(cap/256), npairs); which = 0: query rows, 1: database rows
+__global__ void k_row_norms(PairTable tbl, int which, int n_cap, int dim, int ld, float* __restrict__ out)
 {
+    const mif_match_pair& pr = tbl.p[blockIdx.y];
+    const float* __restrict__ m = which ? pr.d_db : pr.d_q;
+    const int* d_n = which ? pr.d_nd : pr.d_nq;
+    out += (size_t)blockIdx.y * n_cap;
     const int n = d_n ? min(*d_n, n_cap) : n_cap;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -58,19 +68,26 @@ __device__ __forceinline__ void top2_insert(Top2& t, float s, int i)
     }
 }
 
-// grid: (ceil(nq_cap / 128), nsplit). Wave v of block b owns query rows
+// grid: (ceil(nq_cap / 128), nsplit, npairs). Wave v of block b owns query rows
 // [128 b + 32 v, +32); the block walks its share of the database in chunks of
 // 32 rows staged in LDS and shared by the four waves.
 template <int KSTEPS>
-__global__ __launch_bounds__(256) void k_match_partial(const float* __restrict__ Q, int nq_cap,
-                                                       const int* __restrict__ d_nq, const float* __restrict__ D,
-                                                       int nd_cap, const int* __restrict__ d_nd, int dim, int ld,
+__global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int nq_cap, int nd_cap, int dim, int ld,
                                                        const float* __restrict__ qn, const float* __restrict__ dn,
                                                        int nsplit, float* __restrict__ part_s,
                                                        int* __restrict__ part_i)
 {
     constexpr int KP = 2 * KSTEPS + 1;     // odd pitch: conflict-free column reads
     __shared__ float s_b[kDC * KP];
+    const mif_match_pair& pr = tbl.p[blockIdx.z];
+    const float* __restrict__ Q = pr.d_q;
+    const float* __restrict__ D = pr.d_db;
+    const int* d_nq = pr.d_nq;
+    const int* d_nd = pr.d_nd;
+    qn += (size_t)blockIdx.z * nq_cap;
+    dn += (size_t)blockIdx.z * nd_cap;
+    part_s += (size_t)blockIdx.z * nsplit * nq_cap * 2;
+    part_i += (size_t)blockIdx.z * nsplit * nq_cap * 2;
     const int nq = d_nq ? min(*d_nq, nq_cap) : nq_cap;
     const int nd = d_nd ? min(*d_nd, nd_cap) : nd_cap;
     const int tid = threadIdx.x;
@@ -170,11 +187,19 @@ __device__ __forceinline__ float exact_dist(const float* __restrict__ q, const f
     return __builtin_sqrtf(acc);
 }
 
-__global__ void k_match_finalize(const float* __restrict__ Q, int nq_cap, const int* __restrict__ d_nq,
-                                 const float* __restrict__ D, int nd_cap, const int* __restrict__ d_nd, int dim,
-                                 int ld, int nsplit, const float* __restrict__ part_s,
-                                 const int* __restrict__ part_i, int* __restrict__ idx2, float* __restrict__ dist2)
+// grid (ceil(nq_cap/128), npairs)
+__global__ void k_match_finalize(PairTable tbl, int nq_cap, int nd_cap, int dim, int ld, int nsplit,
+                                 const float* __restrict__ part_s, const int* __restrict__ part_i)
 {
+    const mif_match_pair& pr = tbl.p[blockIdx.y];
+    const float* __restrict__ Q = pr.d_q;
+    const float* __restrict__ D = pr.d_db;
+    const int* d_nq = pr.d_nq;
+    const int* d_nd = pr.d_nd;
+    int* __restrict__ idx2 = pr.d_idx2;
+    float* __restrict__ dist2 = pr.d_dist2;
+    part_s += (size_t)blockIdx.y * nsplit * nq_cap * 2;
+    part_i += (size_t)blockIdx.y * nsplit * nq_cap * 2;
     const int nq = d_nq ? min(*d_nq, nq_cap) : nq_cap;
     const int nd = d_nd ? min(*d_nd, nd_cap) : nd_cap;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -203,13 +228,68 @@ __global__ void k_match_finalize(const float* __restrict__ Q, int nq_cap, const 
     dist2[2 * i] = e1; dist2[2 * i + 1] = e2;
 }
 
+// Good-match filters of the reference on the device, one block per pair.
+//   mode 1 (SIFT overload, kpmatch.h:177-202): min_dist starts at 100, max_dist at 0, both
+//     follow the nearest distances; keep dist <= max(2.5 * min_dist, 0.35), all in double.
+//   mode 2 (SURF overload, kpmatch.h:289-297): keep d0 < 0.75f * d1.
+// good[i] = 1/0 per query row; summary = {kept, query rows}; minmax = {min_dist, max_dist}.
+__global__ __launch_bounds__(256) void k_match_filter(PairTable tbl, int nq_cap, int mode)
+{
+    __shared__ double s_min[256], s_max[256];
+    __shared__ int s_cnt[256];
+    const mif_match_pair& pr = tbl.p[blockIdx.x];
+    if (!pr.d_good || !pr.d_summary) return;
+    const int nq = pr.d_nq ? min(*pr.d_nq, nq_cap) : nq_cap;
+    const float* __restrict__ dist2 = pr.d_dist2;
+    const int tid = threadIdx.x;
+    double mn = 100.0, mx = 0.0;
+    if (mode == 1) {
+        for (int i = tid; i < nq; i += 256) {
+            const double d = (double)dist2[2 * i];
+            if (d < mn) mn = d;
+            if (d > mx) mx = d;
+        }
+        s_min[tid] = mn; s_max[tid] = mx;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                if (s_min[tid + st] < s_min[tid]) s_min[tid] = s_min[tid + st];
+                if (s_max[tid + st] > s_max[tid]) s_max[tid] = s_max[tid + st];
+            }
+            __syncthreads();
+        }
+        mn = s_min[0]; mx = s_max[0];
+    }
+    const double lim1 = 2.5 * mn;
+    const double thr = lim1 > 0.35 ? lim1 : 0.35;
+    int cnt = 0;
+    for (int i = tid; i < nq; i += 256) {
+        bool keep;
+        if (mode == 1) keep = (double)dist2[2 * i] <= thr;
+        else keep = dist2[2 * i] < 0.75f * dist2[2 * i + 1];
+        pr.d_good[i] = keep ? 1 : 0;
+        cnt += keep ? 1 : 0;
+    }
+    s_cnt[tid] = cnt;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) s_cnt[tid] += s_cnt[tid + st];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        pr.d_summary[0] = s_cnt[0];
+        pr.d_summary[1] = nq;
+        if (pr.d_minmax) { pr.d_minmax[0] = (float)mn; pr.d_minmax[1] = (float)mx; }
+    }
+}
+
 } // namespace
 
 struct mif_matcher {
-    int device = 0, max_q = 0, max_d = 0, max_split = 1;
-    float* qn = nullptr;
-    float* dn = nullptr;
-    float* part_s = nullptr;
+    int device = 0, max_q = 0, max_d = 0, max_pairs = 1;
+    float* qn = nullptr;       // [pairs][max_q]
+    float* dn = nullptr;       // [pairs][max_d]
+    float* part_s = nullptr;   // [pairs][kMaxSplit][max_q][2]
     int* part_i = nullptr;
     // staging for the host-buffer entry point
     float* d_q = nullptr;
@@ -229,19 +309,23 @@ void free_matcher(mif_matcher* m)
     (void)hipFree(m->d_q); (void)hipFree(m->d_db); (void)hipFree(m->d_idx); (void)hipFree(m->d_dist);
 }
 
-int pick_split(int nq, int nd)
+int pick_split(int nq, int nd, int npairs)
 {
     // enough blocks to cover the chip a few times over, but no split smaller than 8 chunks
-    const int qblocks = (nq + kQT * kWaves - 1) / (kQT * kWaves);
+    const int qblocks = npairs * ((nq + kQT * kWaves - 1) / (kQT * kWaves));
     const int chunks = (nd + kDC - 1) / kDC;
     int split = (1024 + qblocks - 1) / qblocks;
     split = std::min(split, std::max(1, chunks / 8));
     return std::max(1, std::min(split, kMaxSplit));
 }
 
-int match_device(mif_matcher* m, const float* d_q, int nq, const int32_t* d_nq, const float* d_db, int nd,
-                 const int32_t* d_nd, int dim, int ld, int32_t* d_idx2, float* d_dist2, hipStream_t st)
+int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq, int nd, int dim, int ld,
+                int filter_mode, hipStream_t st)
 {
+    if (npairs < 0 || npairs > m->max_pairs) {
+        mif::set_error("match: %d pairs exceed the matcher's capacity of %d", npairs, m->max_pairs);
+        return MIF_ERR_CAPACITY;
+    }
     if (nq < 0 || nd < 0 || nq > m->max_q || nd > m->max_d) {
         mif::set_error("match: %d x %d rows exceed the matcher's capacity %d x %d", nq, nd, m->max_q, m->max_d);
         return MIF_ERR_CAPACITY;
@@ -250,21 +334,43 @@ int match_device(mif_matcher* m, const float* d_q, int nq, const int32_t* d_nq, 
         mif::set_error("match: dim must be 1..128 and ld >= dim (got dim %d, ld %d)", dim, ld);
         return MIF_ERR_INVALID_ARGUMENT;
     }
-    if (nq == 0) return MIF_OK;
-    const int nsplit = pick_split(nq, nd);
-    if (nd > 0) {
-        hipLaunchKernelGGL(k_row_norms, dim3((nd + 255) / 256), dim3(256), 0, st, d_db, nd, d_nd, dim, ld, m->dn);
-        hipLaunchKernelGGL(k_row_norms, dim3((nq + 255) / 256), dim3(256), 0, st, d_q, nq, d_nq, dim, ld, m->qn);
-        dim3 grid((nq + kQT * kWaves - 1) / (kQT * kWaves), nsplit);
-        if (dim <= 64)
-            hipLaunchKernelGGL((k_match_partial<32>), grid, dim3(256), 0, st, d_q, nq, d_nq, d_db, nd, d_nd, dim, ld,
-                               (const float*)m->qn, (const float*)m->dn, nsplit, m->part_s, m->part_i);
-        else
-            hipLaunchKernelGGL((k_match_partial<64>), grid, dim3(256), 0, st, d_q, nq, d_nq, d_db, nd, d_nd, dim, ld,
-                               (const float*)m->qn, (const float*)m->dn, nsplit, m->part_s, m->part_i);
+    if (filter_mode < 0 || filter_mode > 2) {
+        mif::set_error("match: unknown filter mode %d", filter_mode);
+        return MIF_ERR_INVALID_ARGUMENT;
     }
-    hipLaunchKernelGGL(k_match_finalize, dim3((nq + 127) / 128), dim3(128), 0, st, d_q, nq, d_nq, d_db, nd, d_nd, dim,
-                       ld, nsplit, (const float*)m->part_s, (const int*)m->part_i, d_idx2, d_dist2);
+    if (nq == 0 || npairs == 0) return MIF_OK;
+    for (int base = 0; base < npairs; base += kMaxPairs) {
+        const int np = std::min(kMaxPairs, npairs - base);
+        PairTable tbl;
+        memset(&tbl, 0, sizeof(tbl));
+        for (int i = 0; i < np; i++) {
+            tbl.p[i] = pairs[base + i];
+            if (!tbl.p[i].d_q || !tbl.p[i].d_idx2 || !tbl.p[i].d_dist2 || (nd > 0 && !tbl.p[i].d_db)) {
+                mif::set_error("match: pair %d has a NULL pointer", base + i);
+                return MIF_ERR_INVALID_ARGUMENT;
+            }
+        }
+        float* qn = m->qn + (size_t)base * m->max_q;
+        float* dn = m->dn + (size_t)base * m->max_d;
+        float* ps = m->part_s + (size_t)base * kMaxSplit * m->max_q * 2;
+        int* pi = m->part_i + (size_t)base * kMaxSplit * m->max_q * 2;
+        const int nsplit = pick_split(nq, nd, np);
+        if (nd > 0) {
+            hipLaunchKernelGGL(k_row_norms, dim3((nd + 255) / 256, np), dim3(256), 0, st, tbl, 1, nd, dim, ld, dn);
+            hipLaunchKernelGGL(k_row_norms, dim3((nq + 255) / 256, np), dim3(256), 0, st, tbl, 0, nq, dim, ld, qn);
+            dim3 grid((nq + kQT * kWaves - 1) / (kQT * kWaves), nsplit, np);
+            if (dim <= 64)
+                hipLaunchKernelGGL((k_match_partial<32>), grid, dim3(256), 0, st, tbl, nq, nd, dim, ld,
+                                   (const float*)qn, (const float*)dn, nsplit, ps, pi);
+            else
+                hipLaunchKernelGGL((k_match_partial<64>), grid, dim3(256), 0, st, tbl, nq, nd, dim, ld,
+                                   (const float*)qn, (const float*)dn, nsplit, ps, pi);
+        }
+        hipLaunchKernelGGL(k_match_finalize, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim, ld,
+                           nsplit, (const float*)ps, (const int*)pi);
+        if (filter_mode != 0)
+            hipLaunchKernelGGL(k_match_filter, dim3(np), dim3(256), 0, st, tbl, nq, filter_mode);
+    }
     MIF_HIP(hipGetLastError());
     return MIF_OK;
 }
@@ -273,32 +379,37 @@ int match_device(mif_matcher* m, const float* d_q, int nq, const int32_t* d_nq, 
 
 extern "C" {
 
-int mif_match_create(int device, int max_query, int max_database, mif_matcher** out)
+int mif_match_create_batched(int device, int max_query, int max_database, int max_pairs, mif_matcher** out)
 {
     if (!out) return MIF_ERR_INVALID_ARGUMENT;
     *out = nullptr;
-    if (max_query < 1 || max_database < 1) {
+    if (max_query < 1 || max_database < 1 || max_pairs < 1) {
         mif::set_error("mif_match_create: capacities must be positive");
         return MIF_ERR_INVALID_ARGUMENT;
     }
     mif::DeviceGuard guard(device);
     if (!guard.ok) { mif::set_error("mif_match_create: cannot select device %d", device); return MIF_ERR_HIP; }
     mif_matcher* m = new mif_matcher();
-    m->device = device; m->max_q = max_query; m->max_d = max_database;
-    m->max_split = kMaxSplit;
+    m->device = device; m->max_q = max_query; m->max_d = max_database; m->max_pairs = max_pairs;
     auto fail = [&](hipError_t e) {
         mif::set_error("mif_match_create: %s", hipGetErrorString(e));
         free_matcher(m);
         delete m;
         return MIF_ERR_HIP;
     };
+    const size_t P = (size_t)max_pairs;
     hipError_t e;
-    if ((e = hipMalloc(&m->qn, (size_t)max_query * sizeof(float))) != hipSuccess) return fail(e);
-    if ((e = hipMalloc(&m->dn, (size_t)max_database * sizeof(float))) != hipSuccess) return fail(e);
-    if ((e = hipMalloc(&m->part_s, (size_t)kMaxSplit * max_query * 2 * sizeof(float))) != hipSuccess) return fail(e);
-    if ((e = hipMalloc(&m->part_i, (size_t)kMaxSplit * max_query * 2 * sizeof(int))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&m->qn, P * max_query * sizeof(float))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&m->dn, P * max_database * sizeof(float))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&m->part_s, P * kMaxSplit * max_query * 2 * sizeof(float))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&m->part_i, P * kMaxSplit * max_query * 2 * sizeof(int))) != hipSuccess) return fail(e);
     *out = m;
     return MIF_OK;
+}
+
+int mif_match_create(int device, int max_query, int max_database, mif_matcher** out)
+{
+    return mif_match_create_batched(device, max_query, max_database, 1, out);
 }
 
 int mif_match_destroy(mif_matcher* m)
@@ -311,6 +422,17 @@ int mif_match_destroy(mif_matcher* m)
     return MIF_OK;
 }
 
+int mif_match_top2_batch_device(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq, int nd, int dim,
+                                int ld, int filter_mode, void* stream)
+{
+    if (!m || (npairs > 0 && !pairs)) {
+        mif::set_error("mif_match_top2_batch_device: NULL argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(m->device);
+    return match_batch(m, pairs, npairs, nq, nd, dim, ld, filter_mode, (hipStream_t)stream);
+}
+
 int mif_match_top2_device(mif_matcher* m, const float* d_q, int nq, const int32_t* d_nq, const float* d_db, int nd,
                           const int32_t* d_nd, int dim, int ld, int32_t* d_idx2, float* d_dist2, void* stream)
 {
@@ -318,8 +440,11 @@ int mif_match_top2_device(mif_matcher* m, const float* d_q, int nq, const int32_
         mif::set_error("mif_match_top2_device: NULL argument");
         return MIF_ERR_INVALID_ARGUMENT;
     }
+    mif_match_pair pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.d_q = d_q; pr.d_db = d_db; pr.d_nq = d_nq; pr.d_nd = d_nd; pr.d_idx2 = d_idx2; pr.d_dist2 = d_dist2;
     mif::DeviceGuard guard(m->device);
-    return match_device(m, d_q, nq, d_nq, d_db, nd, d_nd, dim, ld, d_idx2, d_dist2, (hipStream_t)stream);
+    return match_batch(m, &pr, 1, nq, nd, dim, ld, 0, (hipStream_t)stream);
 }
 
 int mif_match_top2(mif_matcher* m, const float* q, int nq, const float* db, int nd, int dim, int ld, int32_t* idx2,
@@ -353,7 +478,10 @@ int mif_match_top2(mif_matcher* m, const float* q, int nq, const float* db, int 
     }
     MIF_HIP(hipMemcpy(m->d_q, q, qb, hipMemcpyHostToDevice));
     if (nd > 0) MIF_HIP(hipMemcpy(m->d_db, db, (size_t)nd * ld * sizeof(float), hipMemcpyHostToDevice));
-    const int rc = match_device(m, m->d_q, nq, nullptr, m->d_db, nd, nullptr, dim, ld, m->d_idx, m->d_dist, nullptr);
+    mif_match_pair pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.d_q = m->d_q; pr.d_db = m->d_db; pr.d_idx2 = m->d_idx; pr.d_dist2 = m->d_dist;
+    const int rc = match_batch(m, &pr, 1, nq, nd, dim, ld, 0, nullptr);
     if (rc != MIF_OK) return rc;
     MIF_HIP(hipDeviceSynchronize());
     MIF_HIP(hipMemcpy(idx2, m->d_idx, (size_t)nq * 2 * sizeof(int), hipMemcpyDeviceToHost));

@@ -58,10 +58,13 @@ enum { CNT_OCT0 = 0, CNT_TOTAL = 3, CNT_RAW0 = 4, CNT_STATUS = 7, CNT_WORDS = 8 
 // ---------------------------------------------------------------- base image
 
 // sift.cpp:901-913 copy_pixels_1ch8_to_1ch32 (a host loop in the reference)
+// All kernels below take the frame of a batch from the last grid dimension and
+// address per-frame data at frame * stride.
 __global__ void k_gray_u8(const uint8_t* __restrict__ in, float* __restrict__ out, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (float)in[i] / 255.0f;
+    const size_t f = blockIdx.z;
+    if (i < n) out[f * n + i] = (float)in[f * n + i] / 255.0f;
 }
 
 // sift.cpp:55-72 kColor_interleaved_ch
@@ -69,6 +72,8 @@ __global__ void k_gray_bgr(const uint8_t* __restrict__ in, float* __restrict__ o
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    in += (size_t)blockIdx.z * n * 3;
+    out += (size_t)blockIdx.z * n;
     const float b = (float)in[3 * i], g = (float)in[3 * i + 1], r = (float)in[3 * i + 2];
     const float cb = (float)0.114, cg = (float)0.587, cr = (float)0.299;
     const float val_scale = (float)0.0039215686;
@@ -79,11 +84,13 @@ __global__ void k_gray_bgr(const uint8_t* __restrict__ in, float* __restrict__ o
 // (sift.cpp:1187-1191). `src` is the previous octave's whole pyramid; the
 // source offset 3*(2w)*(2h) and row stride 2w are kept as written, which differs
 // from the previous octave's true geometry when its width or height is odd.
-__global__ void k_decimate(const float* __restrict__ src, float* __restrict__ dst, int w, int h)
+__global__ void k_decimate(const float* __restrict__ src, size_t src_stride, float* __restrict__ dst, int w, int h)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= w || y >= h) return;
+    src += (size_t)blockIdx.z * src_stride;
+    dst += (size_t)blockIdx.z * w * h;
     const int wo = 2 * w;
     const int offset = kIntervals * w * 2 * h * 2;
     dst[y * w + x] = src[(y * 2) * wo + x * 2 + offset];
@@ -108,9 +115,13 @@ __global__ void k_decimate(const float* __restrict__ src, float* __restrict__ ds
 // therefore read LDS with unit stride across lanes (conflict free) and touch
 // each staged value (P+2FR-1)/P resp. (R+2FR-1)/R times instead of 2FR times.
 template <int FR, int TW, int TH, bool DOG>
-__global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ src, float* __restrict__ dst,
-                                                    float* __restrict__ dog, int w, int h, Taps taps)
+__global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ src, size_t src_stride,
+                                                    float* __restrict__ dst, float* __restrict__ dog,
+                                                    size_t pyr_stride, size_t dog_stride, int w, int h, Taps taps)
 {
+    src += (size_t)blockIdx.z * src_stride;
+    dst += (size_t)blockIdx.z * pyr_stride;
+    if (DOG) dog += (size_t)blockIdx.z * dog_stride;
     constexpr int P = 8, R = 8;
     constexpr int EW = TW + 2 * FR - 1;          // staged columns
     constexpr int EH = TH + 2 * FR - 1;          // staged rows
@@ -275,17 +286,20 @@ __device__ bool detect_pixel(const float* __restrict__ dp, const float* __restri
     return true;
 }
 
-// Detection pass: grid (ceil(w/256), h, 3 levels), 256 threads. Every wave
-// tests 64 consecutive pixels of one row and stores its ballot as one 64-bit
-// word of the acceptance bitmask; row totals are accumulated with integer
-// atomics (order independent).
-__global__ __launch_bounds__(256) void k_detect(const float* __restrict__ dog, unsigned long long* __restrict__ mask,
-                                                int* __restrict__ rowcnt, int w, int h, int words, int o)
+// Detection pass: grid (ceil(w/256), h, 3 levels x frames), 256 threads. Every
+// wave tests 64 consecutive pixels of one row and stores its ballot as one
+// 64-bit word of the acceptance bitmask; row totals are accumulated with
+// integer atomics (order independent).
+__global__ __launch_bounds__(256) void k_detect(const float* __restrict__ dog, size_t dog_stride,
+                                                unsigned long long* __restrict__ mask, int* __restrict__ rowcnt,
+                                                int w, int h, int words, int o)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
-    const int s = blockIdx.z + 1;
+    const int f = blockIdx.z / kIntervals;
+    const int s = blockIdx.z - f * kIntervals + 1;
     const size_t items = (size_t)w * h;
+    dog += (size_t)f * dog_stride;
     bool found = false;
     if (x < w) {
         float4 kp;
@@ -294,19 +308,22 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ dog, u
     const unsigned long long m = __ballot(found);
     const int word = x >> 6;                      // uniform over the wave
     if ((threadIdx.x & 63) == 0 && word < words) {
-        const int r = (s - 1) * h + y;
-        mask[(size_t)r * words + word] = m;
+        const size_t r = (size_t)f * kIntervals * h + (s - 1) * h + y;
+        mask[r * words + word] = m;
         if (m) atomicAdd(&rowcnt[r], __popcll(m));
     }
 }
 
-// Exclusive scan of the per-row counts (rows ordered level-major, then y),
-// the octave's keypoint count (cut at max_features = items/100, sift.cpp:1356,
-// 408) and its raw total. One block of 1024 threads.
+// Exclusive scan of a frame's per-row counts (rows ordered level-major, then
+// y), the octave's keypoint count (cut at max_features = items/100,
+// sift.cpp:1356, 408) and its raw total. One block of 1024 threads per frame.
 __global__ __launch_bounds__(1024) void k_scan_rows(const int* __restrict__ rowcnt, int* __restrict__ rowoff,
                                                     int rows, int maxf, int o, int* __restrict__ counts)
 {
     __shared__ int s_part[1024];
+    rowcnt += (size_t)blockIdx.x * rows;
+    rowoff += (size_t)blockIdx.x * rows;
+    counts += (size_t)blockIdx.x * CNT_WORDS;
     const int tid = threadIdx.x;
     const int per = (rows + 1023) / 1024;
     const int lo = tid * per;
@@ -344,38 +361,72 @@ __device__ __forceinline__ int octave_base(const int* counts, int o)
     return b;
 }
 
-// Emission pass: one wave per (level, row). Accepted pixels are re-refined (the
-// refinement is a pure function of the DoG stack) and written at
-// base(octave) + rowoff + rank-in-row, i.e. in raster order.
-__global__ __launch_bounds__(256) void k_emit(const float* __restrict__ dog,
+// Emission pass: one wave per (frame, level, row). The row's accepted pixels
+// are dealt to the lanes (lane j takes the j-th set bit of the row's bitmask),
+// re-refined (the refinement is a pure function of the DoG stack) and written at
+// base(octave) + rowoff + j, i.e. in raster order.
+__global__ __launch_bounds__(256) void k_emit(const float* __restrict__ dog, size_t dog_stride,
                                               const unsigned long long* __restrict__ mask,
                                               const int* __restrict__ rowcnt, const int* __restrict__ rowoff, int w,
-                                              int h, int words, int o, int maxf, const int* __restrict__ counts,
-                                              float4* __restrict__ kp)
+                                              int h, int words, int o, int maxf, int cap,
+                                              const int* __restrict__ counts, float4* __restrict__ kp)
 {
     const int lane = threadIdx.x & 63;
+    const int rows = kIntervals * h;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= kIntervals * h) return;
-    if (rowcnt[r] == 0) return;
+    const int f = blockIdx.y;
+    if (r >= rows) return;
+    const size_t fr = (size_t)f * rows + r;
+    const int cnt = rowcnt[fr];
+    if (cnt == 0) return;
     const int s = r / h + 1;
     const int y = r - (s - 1) * h;
     const size_t items = (size_t)w * h;
+    dog += (size_t)f * dog_stride;
+    counts += (size_t)f * CNT_WORDS;
+    kp += (size_t)f * cap;
     const int base = octave_base(counts, o);
-    int pos = rowoff[r];
-    for (int word = 0; word < words; word++) {
-        const unsigned long long m = mask[(size_t)r * words + word];
-        if (m == 0) continue;
-        if ((m >> lane) & 1ull) {
-            const int rank = __popcll(m & ((1ull << lane) - 1ull));
-            const int p = pos + rank;
-            if (p < maxf) {
-                float4 out;
-                detect_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o,
-                             word * 64 + lane, y, &out);
-                kp[base + p] = out;
+    const int off = rowoff[fr];
+    const unsigned long long* mrow = mask + fr * words;
+    int seen = 0;                                       // set bits in the words before this group
+    for (int w0 = 0; w0 < words && seen < cnt; w0 += 64) {
+        const unsigned long long m = (w0 + lane < words) ? mrow[w0 + lane] : 0ull;
+        const int c = __popcll(m);
+        int incl = c;                                   // inclusive prefix of the popcounts
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        const int group = __shfl(incl, 63);
+        for (int j0 = 0; j0 < group; j0 += 64) {
+            const int j = j0 + lane;                    // my set bit within this group of words
+            int myword = -1;
+            unsigned long long mym = 0ull;
+            int before = 0;
+            for (int k = 0; k < 64; k++) {
+                const int ik = __shfl(incl, k);
+                const int ck = __shfl(c, k);
+                const unsigned long long mk = __shfl(m, k);
+                if (myword < 0 && j < group && j >= ik - ck && j < ik) {
+                    myword = k;
+                    mym = mk;
+                    before = ik - ck;
+                }
+            }
+            if (myword >= 0) {
+                for (int t = j - before; t > 0; t--) mym &= mym - 1ull;   // drop the lower set bits
+                const int bit = __ffsll((long long)mym) - 1;
+                const int p = off + seen + j;
+                if (p < maxf) {
+                    float4 out;
+                    detect_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o,
+                                 (w0 + myword) * 64 + bit, y, &out);
+                    kp[base + p] = out;
+                }
             }
         }
-        pos += __popcll(m);
+        seen += group;
     }
 }
 
@@ -387,51 +438,59 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ dog,
 // with the reference's tree (8, 4, 2, 1) and lane 0 smooths and picks the last
 // qualifying peak.
 __global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ kp, const float* __restrict__ pyr,
-                                                    int w, int h, int o, const int* __restrict__ counts,
-                                                    float* __restrict__ orient)
+                                                    size_t pyr_stride, int w, int h, int o, int cap,
+                                                    const int* __restrict__ counts, float* __restrict__ orient)
 {
     __shared__ float s_hist[4][kOriLanes][kOriBins + 1];
+    const int f = blockIdx.y;
+    counts += (size_t)f * CNT_WORDS;
+    kp += (size_t)f * cap;
+    orient += (size_t)f * cap;
+    pyr += (size_t)f * pyr_stride;
     const int grp = threadIdx.x >> 4;
     const int lid = threadIdx.x & 15;
     const int n = counts[CNT_OCT0 + o];
+    if ((int)blockIdx.x * 4 >= n) return;               // uniform over the block
     const int g = blockIdx.x * 4 + grp;
     const bool active = g < n;
     const int gi = octave_base(counts, o) + g;
     float* hist = s_hist[grp][lid];
     for (int i = 0; i < kOriBins; i++) hist[i] = 0.0f;
 
-    int x = 0, y = 0;
     if (active) {
-        const float4 f = kp[gi];
-        const float exp_denom = (float)((double)f.z * K_ORI_SIG_FCTR);
-        const int rad = (int)mif_round(K_ORI_RADIUS * (double)f.z);
+        const float4 f4 = kp[gi];
+        const float exp_denom = (float)((double)f4.z * K_ORI_SIG_FCTR);
+        const int rad = (int)mif_round(K_ORI_RADIUS * (double)f4.z);
         const float exp_factor = -0.5f / (exp_denom * exp_denom);
         const int sq_thres = rad * rad;
-        const int offset_py = (int)((float)(w * h) * f.w);
+        const int offset_py = (int)((float)(w * h) * f4.w);
         const float p2o = mif_pow2i(o);
-        x = (int)(f.x / p2o);
-        y = (int)(f.y / p2o);
+        const int x = (int)(f4.x / p2o);
+        const int y = (int)(f4.y / p2o);
         const int xmin = max(1, x - rad), ymin = max(1, y - rad);
         const int xmax = min(w - 2, x + rad), ymax = min(h - 2, y + rad);
         const int wx = xmax - xmin + 1, hy = ymax - ymin + 1;
         const int loops = wx * hy;
         const float* img = pyr + offset_py;
+        // window pixel i = (i / wx + ymin, i % wx + xmin), i = lid, lid + 16, ...
+        int yy = lid / wx + ymin;
+        int xx = lid % wx + xmin;
         for (int i = lid; i < loops; i += kOriLanes) {
-            const int yy = i / wx + ymin;
-            const int xx = i % wx + xmin;
             if (xx > 0 && xx < w - 1 && yy > 0 && yy < h - 1) {
                 float dx = img[yy * w + xx + 1] - img[yy * w + xx - 1];
                 float dy = img[(yy - 1) * w + xx] - img[(yy + 1) * w + xx];
-                const float grad = __builtin_sqrtf(dx * dx + dy * dy);
-                const float theta = mif_atan2f(dy, dx);
-                dx = (float)(xx - x);
-                dy = (float)(yy - y);
-                const int sq_dist = (int)(dx * dx + dy * dy);
-                if (sq_dist > sq_thres) continue;
-                int bin = (int)mif_round((kOriBins * ((double)theta + K_M_PI)) / K_M_PI2);
-                bin = (bin < kOriBins) ? bin : 0;
-                hist[bin] += grad * mif_expf((float)sq_dist * exp_factor);
+                const float ddx = (float)(xx - x), ddy = (float)(yy - y);
+                const int sq_dist = (int)(ddx * ddx + ddy * ddy);
+                if (sq_dist <= sq_thres) {
+                    const float grad = __builtin_sqrtf(dx * dx + dy * dy);
+                    const float theta = mif_atan2f(dy, dx);
+                    int bin = (int)mif_round((kOriBins * ((double)theta + K_M_PI)) / K_M_PI2);
+                    bin = (bin < kOriBins) ? bin : 0;
+                    hist[bin] += grad * mif_expf((float)sq_dist * exp_factor);
+                }
             }
+            xx += kOriLanes;
+            while (xx > xmax) { xx -= wx; yy++; }
         }
     }
     __syncthreads();
@@ -494,13 +553,20 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
 // Normalisation sums the 128 squares sequentially, as the reference's
 // one-thread-per-keypoint kernel does.
 __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ kp, const float* __restrict__ orient,
-                                                    const float* __restrict__ pyr, int w, int h, int o,
-                                                    const int* __restrict__ counts, float* __restrict__ desc)
+                                                    const float* __restrict__ pyr, size_t pyr_stride, int w, int h,
+                                                    int o, int cap, const int* __restrict__ counts,
+                                                    float* __restrict__ desc)
 {
     __shared__ float s_des[16][8][9];
     __shared__ float s_val[128];
     __shared__ float s_sq[128];
     __shared__ float s_norm;
+    const int f = blockIdx.y;
+    counts += (size_t)f * CNT_WORDS;
+    kp += (size_t)f * cap;
+    orient += (size_t)f * cap;
+    desc += (size_t)f * cap * 128;
+    pyr += (size_t)f * pyr_stride;
     const int n = counts[CNT_OCT0 + o];
     if ((int)blockIdx.x >= n) return;                  // uniform over the block
     const int gi = octave_base(counts, o) + blockIdx.x;
@@ -512,13 +578,13 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = 0.0f;
 
-    const float4 f = kp[gi];
+    const float4 f4 = kp[gi];
     const float p2o = mif_pow2i(o);
-    const int x = (int)(f.x / p2o);
-    const int y = (int)(f.y / p2o);
-    const float* img = pyr + (int)((float)(w * h) * f.w);
+    const int x = (int)(f4.x / p2o);
+    const int y = (int)(f4.y / p2o);
+    const float* img = pyr + (int)((float)(w * h) * f4.w);
     const float ang = -orient[gi];
-    const float spt = (float)fabs((double)f.z * 3.0);
+    const float spt = (float)fabs((double)f4.z * 3.0);
     float sn, cs;
     mif_sincosf(ang, &sn, &cs);
     const float cspt = cs * spt, sspt = sn * spt;
@@ -538,33 +604,38 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
     // a window that is empty in both directions has a positive wx*hy in the
     // reference and would index outside the image; it is treated as empty
     const int loops = (wx > 0 && hy > 0) ? wx * hy : 0;
-    for (int i = lid; i < loops; i += 8) {
-        const int yy = i / wx + ymin;
-        const int xx = i % wx + xmin;
-        float dx = (float)xx - ptx;
-        float dy = (float)yy - pty;
-        const float nx = crspt * dx + srspt * dy;
-        const float ny = crspt * dy - srspt * dx;
-        const float nxn = mif_fabsf(nx), nyn = mif_fabsf(ny);
-        if (nxn < 1.0f && nyn < 1.0f) {
-            dx = img[yy * w + xx + 1] - img[yy * w + xx - 1];
-            dy = img[(yy + 1) * w + xx] - img[(yy - 1) * w + xx];
-            const float mod = __builtin_sqrtf(dx * dx + dy * dy);
-            float th = mif_atan2f(dy, dx);
-            const float dnx = nx + offx, dny = ny + offy;
-            const float ww = mif_expf(-0.125f * (dnx * dnx + dny * dny));
-            const float wwx = (float)(1.0 - (double)nxn);
-            const float wwy = (float)(1.0 - (double)nyn);
-            const float wgt = ww * wwx * wwy * mod;
-            th -= ang;
-            while (th < 0.0f) th = (float)((double)th + K_M_PI2);
-            while ((double)th >= K_M_PI2) th = (float)((double)th - K_M_PI2);
-            const float tth = (float)((double)th * K_RPI);
-            const int fo0 = (int)__builtin_floorf(tth);
-            const float do0 = tth - (float)fo0;
-            const int fo = fo0 % 8;
-            d[fo] += (1.0f - do0) * wgt;
-            d[fo + 1] += do0 * wgt;
+    if (loops > 0) {
+        // window pixel i = (i / wx + ymin, i % wx + xmin), i = lid, lid + 8, ...
+        int yy = lid / wx + ymin;
+        int xx = lid % wx + xmin;
+        for (int i = lid; i < loops; i += 8) {
+            float dx = (float)xx - ptx;
+            float dy = (float)yy - pty;
+            const float nx = crspt * dx + srspt * dy;
+            const float ny = crspt * dy - srspt * dx;
+            const float nxn = mif_fabsf(nx), nyn = mif_fabsf(ny);
+            if (nxn < 1.0f && nyn < 1.0f) {
+                dx = img[yy * w + xx + 1] - img[yy * w + xx - 1];
+                dy = img[(yy + 1) * w + xx] - img[(yy - 1) * w + xx];
+                const float mod = __builtin_sqrtf(dx * dx + dy * dy);
+                float th = mif_atan2f(dy, dx);
+                const float dnx = nx + offx, dny = ny + offy;
+                const float ww = mif_expf(-0.125f * (dnx * dnx + dny * dny));
+                const float wwx = (float)(1.0 - (double)nxn);
+                const float wwy = (float)(1.0 - (double)nyn);
+                const float wgt = ww * wwx * wwy * mod;
+                th -= ang;
+                while (th < 0.0f) th = (float)((double)th + K_M_PI2);
+                while ((double)th >= K_M_PI2) th = (float)((double)th - K_M_PI2);
+                const float tth = (float)((double)th * K_RPI);
+                const int fo0 = (int)__builtin_floorf(tth);
+                const float do0 = tth - (float)fo0;
+                const int fo = fo0 % 8;
+                d[fo] += (1.0f - do0) * wgt;
+                d[fo + 1] += do0 * wgt;
+            }
+            xx += 8;
+            while (xx > xmax) { xx -= wx; yy++; }
         }
     }
     d[0] += d[8];
@@ -596,12 +667,14 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
     desc[(size_t)gi * 128 + tid] = clampf(v1, 0.0f, 255.0f);
 }
 
-// After the last octave: status = 0, or -1 when an octave found nothing
-// (sift.cpp:1257-1258); in that case all counts are cleared so that no stage
-// downstream consumes a partial frame.
-__global__ void k_finish(int* counts, int want_desc)
+// After the last octave, one thread per frame: status = 0, or -1 when an
+// octave found nothing (sift.cpp:1257-1258); in that case the frame's counts
+// are cleared so that no stage downstream consumes a partial frame.
+__global__ void k_finish(int* counts, int nframes, int want_desc)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    counts += (size_t)f * CNT_WORDS;
     int status = 0;
     if (want_desc)
         for (int o = 0; o < kOctaves; o++)
@@ -617,6 +690,8 @@ __global__ void k_finish(int* counts, int want_desc)
 
 struct OctaveBuf {
     int w = 0, h = 0, maxf = 0, words = 0, rows = 0;
+    size_t items = 0;
+    // every buffer holds `batch` frames back to back
     float* base = nullptr;                 // [h][w] input of level 0
     float* pyr = nullptr;                  // [6][h][w]
     float* dog = nullptr;                  // [5][h][w]
@@ -662,43 +737,50 @@ void build_taps(std::vector<float> taps[kLevels], int fr[kLevels])
 } // namespace
 
 struct mif_sift {
-    int device = 0, W = 0, H = 0, C = 1, cap = 0;
+    int device = 0, W = 0, H = 0, C = 1, cap = 0, batch = 1;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_dep = nullptr;
     OctaveBuf oct[kOctaves];
-    uint8_t* d_pixels = nullptr;           // staging for the host-buffer entry point
-    float4* kp = nullptr;
-    float* orient = nullptr;
-    float* desc = nullptr;
-    int* counts = nullptr;
-    int* h_counts = nullptr;               // pinned
+    uint8_t* d_pixels = nullptr;           // staging for the host-buffer entry point (one frame)
+    float4* kp = nullptr;                  // [batch][cap]
+    float* orient = nullptr;               // [batch][cap]
+    float* desc = nullptr;                 // [batch][cap][128]
+    int* counts = nullptr;                 // [batch][8]
+    int* h_counts = nullptr;               // pinned, [batch][8]
     std::vector<float> taps[kLevels];
     int fr[kLevels];
     Taps ktaps[kLevels];
     bool frame_done = false;
+    // optional per-stage timing: events at the stage boundaries of every octave
+    bool timing = false, timed_frame = false, timed_desc = false;
+    hipEvent_t ev_stage[kOctaves][MIF_SIFT_STAGES + 1] = {};
 };
 
 namespace {
 
 template <int FR>
-void launch_blur_fr(const float* src, float* dst, float* dog, int w, int h, const Taps& t, hipStream_t st)
+void launch_blur_fr(const float* src, size_t src_stride, float* dst, float* dog, size_t pyr_stride, size_t dog_stride,
+                    int w, int h, int nframes, const Taps& t, hipStream_t st)
 {
     constexpr int TW = 64, TH = 64;
-    dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH);
+    dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, nframes);
     if (dog)
-        hipLaunchKernelGGL((k_blur_level<FR, TW, TH, true>), grid, dim3(256), 0, st, src, dst, dog, w, h, t);
+        hipLaunchKernelGGL((k_blur_level<FR, TW, TH, true>), grid, dim3(256), 0, st, src, src_stride, dst, dog,
+                           pyr_stride, dog_stride, w, h, t);
     else
-        hipLaunchKernelGGL((k_blur_level<FR, TW, TH, false>), grid, dim3(256), 0, st, src, dst, dog, w, h, t);
+        hipLaunchKernelGGL((k_blur_level<FR, TW, TH, false>), grid, dim3(256), 0, st, src, src_stride, dst, dog,
+                           pyr_stride, dog_stride, w, h, t);
 }
 
-int launch_blur(int fr, const float* src, float* dst, float* dog, int w, int h, const Taps& t, hipStream_t st)
+int launch_blur(int fr, const float* src, size_t src_stride, float* dst, float* dog, size_t pyr_stride,
+                size_t dog_stride, int w, int h, int nframes, const Taps& t, hipStream_t st)
 {
     switch (fr) {
-    case 5: launch_blur_fr<5>(src, dst, dog, w, h, t, st); break;
-    case 6: launch_blur_fr<6>(src, dst, dog, w, h, t, st); break;
-    case 7: launch_blur_fr<7>(src, dst, dog, w, h, t, st); break;
-    case 9: launch_blur_fr<9>(src, dst, dog, w, h, t, st); break;
-    case 11: launch_blur_fr<11>(src, dst, dog, w, h, t, st); break;
+    case 5: launch_blur_fr<5>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, st); break;
+    case 6: launch_blur_fr<6>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, st); break;
+    case 7: launch_blur_fr<7>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, st); break;
+    case 9: launch_blur_fr<9>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, st); break;
+    case 11: launch_blur_fr<11>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, st); break;
     default:
         mif::set_error("no blur kernel for tap radius %d", fr);
         return MIF_ERR_UNSUPPORTED;
@@ -706,54 +788,69 @@ int launch_blur(int fr, const float* src, float* dst, float* dog, int w, int h, 
     return MIF_OK;
 }
 
-int enqueue_frame(mif_sift* s, const void* d_pixels, int want_desc)
+int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc)
 {
     hipStream_t st = s->stream;
+    const int nf = nframes;
     MIF_HIP(hipEventRecord(s->ev0, st));
-    MIF_HIP(hipMemsetAsync(s->counts, 0, CNT_WORDS * sizeof(int), st));
+    MIF_HIP(hipMemsetAsync(s->counts, 0, (size_t)nf * CNT_WORDS * sizeof(int), st));
+    const bool tm = s->timing;
+    s->timed_frame = false;
     for (int o = 0; o < kOctaves; o++) {
         OctaveBuf& O = s->oct[o];
-        const int items = O.w * O.h;
+        const int items = (int)O.items;
         if (items == 0) continue;
+        const size_t pyr_stride = O.items * kLevels, dog_stride = O.items * (kLevels - 1);
+        if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][0], st));
         if (o == 0) {
             if (s->C == 3)
-                hipLaunchKernelGGL(k_gray_bgr, dim3((items + 255) / 256), dim3(256), 0, st,
+                hipLaunchKernelGGL(k_gray_bgr, dim3((items + 255) / 256, 1, nf), dim3(256), 0, st,
                                    (const uint8_t*)d_pixels, O.base, items);
             else
-                hipLaunchKernelGGL(k_gray_u8, dim3((items + 255) / 256), dim3(256), 0, st,
+                hipLaunchKernelGGL(k_gray_u8, dim3((items + 255) / 256, 1, nf), dim3(256), 0, st,
                                    (const uint8_t*)d_pixels, O.base, items);
         } else {
-            hipLaunchKernelGGL(k_decimate, dim3((O.w + 255) / 256, O.h), dim3(256), 0, st,
-                               (const float*)s->oct[o - 1].pyr, O.base, O.w, O.h);
+            hipLaunchKernelGGL(k_decimate, dim3((O.w + 255) / 256, O.h, nf), dim3(256), 0, st,
+                               (const float*)s->oct[o - 1].pyr, s->oct[o - 1].items * kLevels, O.base, O.w, O.h);
         }
+        if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][1], st));
         // level 0 blurs the base image with sigma 1.6; level l >= 1 blurs level l-1
         // (sift.cpp:1196-1218) and yields DoG[l-1] = level l - level l-1 (sift.cpp:256-260)
         for (int l = 0; l < kLevels; l++) {
             const float* src = (l == 0) ? O.base : O.pyr + (size_t)(l - 1) * items;
+            const size_t src_stride = (l == 0) ? O.items : pyr_stride;
             float* dst = O.pyr + (size_t)l * items;
             float* dog = (l == 0) ? nullptr : O.dog + (size_t)(l - 1) * items;
-            const int rc = launch_blur(s->fr[l], src, dst, dog, O.w, O.h, s->ktaps[l], st);
+            const int rc = launch_blur(s->fr[l], src, src_stride, dst, dog, pyr_stride, dog_stride, O.w, O.h, nf,
+                                       s->ktaps[l], st);
             if (rc != MIF_OK) return rc;
         }
-        MIF_HIP(hipMemsetAsync(O.rowcnt, 0, (size_t)O.rows * sizeof(int), st));
-        hipLaunchKernelGGL(k_detect, dim3((O.w + 255) / 256, O.h, kIntervals), dim3(256), 0, st,
-                           (const float*)O.dog, O.mask, O.rowcnt, O.w, O.h, O.words, o);
-        hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, st, (const int*)O.rowcnt, O.rowoff, O.rows, O.maxf,
+        if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][2], st));
+        MIF_HIP(hipMemsetAsync(O.rowcnt, 0, (size_t)nf * O.rows * sizeof(int), st));
+        hipLaunchKernelGGL(k_detect, dim3((O.w + 255) / 256, O.h, kIntervals * nf), dim3(256), 0, st,
+                           (const float*)O.dog, dog_stride, O.mask, O.rowcnt, O.w, O.h, O.words, o);
+        hipLaunchKernelGGL(k_scan_rows, dim3(nf), dim3(1024), 0, st, (const int*)O.rowcnt, O.rowoff, O.rows, O.maxf,
                            o, s->counts);
         if (O.maxf > 0) {
-            hipLaunchKernelGGL(k_emit, dim3((O.rows + 3) / 4), dim3(256), 0, st, (const float*)O.dog,
+            hipLaunchKernelGGL(k_emit, dim3((O.rows + 3) / 4, nf), dim3(256), 0, st, (const float*)O.dog, dog_stride,
                                (const unsigned long long*)O.mask, (const int*)O.rowcnt, (const int*)O.rowoff, O.w,
-                               O.h, O.words, o, O.maxf, (const int*)s->counts, s->kp);
+                               O.h, O.words, o, O.maxf, s->cap, (const int*)s->counts, s->kp);
+            if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][3], st));
             if (want_desc) {
-                hipLaunchKernelGGL(k_orientation, dim3((O.maxf + 3) / 4), dim3(64), 0, st, (const float4*)s->kp,
-                                   (const float*)O.pyr, O.w, O.h, o, (const int*)s->counts, s->orient);
-                hipLaunchKernelGGL(k_descriptor, dim3(O.maxf), dim3(128), 0, st, (const float4*)s->kp,
-                                   (const float*)s->orient, (const float*)O.pyr, O.w, O.h, o,
+                hipLaunchKernelGGL(k_orientation, dim3((O.maxf + 3) / 4, nf), dim3(64), 0, st, (const float4*)s->kp,
+                                   (const float*)O.pyr, pyr_stride, O.w, O.h, o, s->cap, (const int*)s->counts,
+                                   s->orient);
+                hipLaunchKernelGGL(k_descriptor, dim3(O.maxf, nf), dim3(128), 0, st, (const float4*)s->kp,
+                                   (const float*)s->orient, (const float*)O.pyr, pyr_stride, O.w, O.h, o, s->cap,
                                    (const int*)s->counts, s->desc);
             }
+        } else if (tm) {
+            MIF_HIP(hipEventRecord(s->ev_stage[o][3], st));
         }
+        if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][4], st));
     }
-    hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, st, s->counts, want_desc);
+    if (tm) { s->timed_frame = true; s->timed_desc = want_desc != 0; }
+    hipLaunchKernelGGL(k_finish, dim3((nf + 63) / 64), dim3(64), 0, st, s->counts, nf, want_desc);
     MIF_HIP(hipGetLastError());
     MIF_HIP(hipEventRecord(s->ev1, st));
     s->frame_done = true;
@@ -772,41 +869,48 @@ void free_all(mif_sift* s)
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->ev_dep) (void)hipEventDestroy(s->ev_dep);
+    for (int o = 0; o < kOctaves; o++)
+        for (int i = 0; i <= MIF_SIFT_STAGES; i++)
+            if (s->ev_stage[o][i]) (void)hipEventDestroy(s->ev_stage[o][i]);
     if (s->stream) (void)hipStreamDestroy(s->stream);
 }
 
 int create_impl(mif_sift* s)
 {
+    const size_t B = (size_t)s->batch;
     MIF_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     MIF_HIP(hipEventCreate(&s->ev0));
     MIF_HIP(hipEventCreate(&s->ev1));
+    MIF_HIP(hipEventCreateWithFlags(&s->ev_dep, hipEventDisableTiming));
     s->cap = 0;
     for (int o = 0; o < kOctaves; o++) {
         OctaveBuf& O = s->oct[o];
         // sift.cpp:1313-1314: size_t = int / std::pow(2, id)
         O.w = (int)(size_t)(s->W / std::pow(2, o));
         O.h = (int)(size_t)(s->H / std::pow(2, o));
-        const size_t items = (size_t)O.w * O.h;
-        O.maxf = (int)(items / 100);       // sift.cpp:1356
+        O.items = (size_t)O.w * O.h;
+        O.maxf = (int)(O.items / 100);     // sift.cpp:1356
         O.words = (O.w + 63) / 64;
         O.rows = kIntervals * O.h;
         s->cap += O.maxf;
-        if (items == 0) continue;
-        MIF_HIP(hipMalloc(&O.base, items * sizeof(float)));
-        MIF_HIP(hipMalloc(&O.pyr, items * kLevels * sizeof(float)));
-        MIF_HIP(hipMalloc(&O.dog, items * (kLevels - 1) * sizeof(float)));
-        MIF_HIP(hipMalloc(&O.mask, (size_t)O.rows * O.words * sizeof(unsigned long long)));
-        MIF_HIP(hipMalloc(&O.rowcnt, (size_t)O.rows * sizeof(int)));
-        MIF_HIP(hipMalloc(&O.rowoff, (size_t)O.rows * sizeof(int)));
+        if (O.items == 0) continue;
+        MIF_HIP(hipMalloc(&O.base, B * O.items * sizeof(float)));
+        MIF_HIP(hipMalloc(&O.pyr, B * O.items * kLevels * sizeof(float)));
+        MIF_HIP(hipMalloc(&O.dog, B * O.items * (kLevels - 1) * sizeof(float)));
+        MIF_HIP(hipMalloc(&O.mask, B * O.rows * O.words * sizeof(unsigned long long)));
+        MIF_HIP(hipMalloc(&O.rowcnt, B * O.rows * sizeof(int)));
+        MIF_HIP(hipMalloc(&O.rowoff, B * O.rows * sizeof(int)));
     }
-    const size_t cap = (size_t)(s->cap > 0 ? s->cap : 1);
+    if (s->cap < 1) s->cap = 1;            // keep every result buffer addressable
+    const size_t cap = (size_t)s->cap;
     MIF_HIP(hipMalloc(&s->d_pixels, (size_t)s->W * s->H * s->C));
-    MIF_HIP(hipMalloc(&s->kp, cap * sizeof(float4)));
-    MIF_HIP(hipMalloc(&s->orient, cap * sizeof(float)));
-    MIF_HIP(hipMalloc(&s->desc, cap * 128 * sizeof(float)));
-    MIF_HIP(hipMalloc(&s->counts, CNT_WORDS * sizeof(int)));
-    MIF_HIP(hipMemset(s->counts, 0, CNT_WORDS * sizeof(int)));
-    MIF_HIP(hipHostMalloc(&s->h_counts, CNT_WORDS * sizeof(int)));
+    MIF_HIP(hipMalloc(&s->kp, B * cap * sizeof(float4)));
+    MIF_HIP(hipMalloc(&s->orient, B * cap * sizeof(float)));
+    MIF_HIP(hipMalloc(&s->desc, B * cap * 128 * sizeof(float)));
+    MIF_HIP(hipMalloc(&s->counts, B * CNT_WORDS * sizeof(int)));
+    MIF_HIP(hipMemset(s->counts, 0, B * CNT_WORDS * sizeof(int)));
+    MIF_HIP(hipHostMalloc(&s->h_counts, B * CNT_WORDS * sizeof(int)));
     build_taps(s->taps, s->fr);
     for (int l = 0; l < kLevels; l++) {
         memset(&s->ktaps[l], 0, sizeof(Taps));
@@ -821,7 +925,8 @@ int create_impl(mif_sift* s)
 
 int fetch_counts(mif_sift* s)
 {
-    MIF_HIP(hipMemcpyAsync(s->h_counts, s->counts, CNT_WORDS * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    MIF_HIP(hipMemcpyAsync(s->h_counts, s->counts, (size_t)s->batch * CNT_WORDS * sizeof(int), hipMemcpyDeviceToHost,
+                           s->stream));
     MIF_HIP(hipStreamSynchronize(s->stream));
     return MIF_OK;
 }
@@ -830,16 +935,17 @@ int fetch_counts(mif_sift* s)
 
 extern "C" {
 
-int mif_sift_create(int device, int width, int height, int channels, int up_scale, mif_sift** out)
+int mif_sift_create_batched(int device, int width, int height, int channels, int up_scale, int batch,
+                            mif_sift** out)
 {
     if (!out) { mif::set_error("mif_sift_create: out is NULL"); return MIF_ERR_INVALID_ARGUMENT; }
     *out = nullptr;
-    if (width <= 0 || height <= 0 || (channels != 1 && channels != 3)) {
-        mif::set_error("mif_sift_create: bad geometry %dx%dx%d", width, height, channels);
+    if (width <= 0 || height <= 0 || (channels != 1 && channels != 3) || batch < 1 || batch > 1024) {
+        mif::set_error("mif_sift_create: bad geometry %dx%dx%d, batch %d", width, height, channels, batch);
         return MIF_ERR_INVALID_ARGUMENT;
     }
-    if ((long long)width * height * 3 >= (1ll << 31)) {
-        mif::set_error("mif_sift_create: image too large for 32-bit pixel indices");
+    if ((long long)width * height * 3 >= (1ll << 31) || (long long)height * batch * 3 > 65535ll * 64) {
+        mif::set_error("mif_sift_create: image or batch too large");
         return MIF_ERR_INVALID_ARGUMENT;
     }
     if (up_scale) {
@@ -849,11 +955,16 @@ int mif_sift_create(int device, int width, int height, int channels, int up_scal
     mif::DeviceGuard guard(device);
     if (!guard.ok) { mif::set_error("mif_sift_create: cannot select device %d", device); return MIF_ERR_HIP; }
     mif_sift* s = new mif_sift();
-    s->device = device; s->W = width; s->H = height; s->C = channels;
+    s->device = device; s->W = width; s->H = height; s->C = channels; s->batch = batch;
     const int rc = create_impl(s);
     if (rc != MIF_OK) { free_all(s); delete s; return rc; }
     *out = s;
     return MIF_OK;
+}
+
+int mif_sift_create(int device, int width, int height, int channels, int up_scale, mif_sift** out)
+{
+    return mif_sift_create_batched(device, width, height, channels, up_scale, 1, out);
 }
 
 int mif_sift_destroy(mif_sift* s)
@@ -876,12 +987,17 @@ int mif_sift_octave_info(const mif_sift* s, int octave, int* width, int* height,
 }
 
 int mif_sift_capacity(const mif_sift* s) { return s ? s->cap : MIF_ERR_INVALID_ARGUMENT; }
+int mif_sift_batch(const mif_sift* s) { return s ? s->batch : MIF_ERR_INVALID_ARGUMENT; }
 
-int mif_sift_enqueue(mif_sift* s, const void* d_pixels, int want_descriptors)
+int mif_sift_enqueue(mif_sift* s, const void* d_pixels, int nframes, int want_descriptors)
 {
     if (!s || !d_pixels) { mif::set_error("mif_sift_enqueue: NULL argument"); return MIF_ERR_INVALID_ARGUMENT; }
+    if (nframes < 1 || nframes > s->batch) {
+        mif::set_error("mif_sift_enqueue: %d frames do not fit the handle's batch of %d", nframes, s->batch);
+        return MIF_ERR_CAPACITY;
+    }
     mif::DeviceGuard guard(s->device);
-    return enqueue_frame(s, d_pixels, want_descriptors);
+    return enqueue_frames(s, d_pixels, nframes, want_descriptors);
 }
 
 int mif_sift_sync(mif_sift* s)
@@ -889,6 +1005,16 @@ int mif_sift_sync(mif_sift* s)
     if (!s) return MIF_ERR_INVALID_ARGUMENT;
     mif::DeviceGuard guard(s->device);
     MIF_HIP(hipStreamSynchronize(s->stream));
+    return MIF_OK;
+}
+
+int mif_sift_wait_for(mif_sift* s, mif_sift* other)
+{
+    if (!s || !other) return MIF_ERR_INVALID_ARGUMENT;
+    if (s == other) return MIF_OK;
+    mif::DeviceGuard guard(s->device);
+    MIF_HIP(hipEventRecord(other->ev_dep, other->stream));
+    MIF_HIP(hipStreamWaitEvent(s->stream, other->ev_dep, 0));
     return MIF_OK;
 }
 
@@ -905,17 +1031,18 @@ int mif_sift_device_results(mif_sift* s, void** d_keypoints, void** d_orientatio
 
 void* mif_sift_stream(mif_sift* s) { return s ? (void*)s->stream : nullptr; }
 
-int mif_sift_read_counts(mif_sift* s, int counts[MIF_SIFT_OCTAVES], int raw_counts[MIF_SIFT_OCTAVES])
+int mif_sift_read_counts(mif_sift* s, int frame, int counts[MIF_SIFT_OCTAVES], int raw_counts[MIF_SIFT_OCTAVES])
 {
-    if (!s) return MIF_ERR_INVALID_ARGUMENT;
+    if (!s || frame < 0 || frame >= s->batch) return MIF_ERR_INVALID_ARGUMENT;
     mif::DeviceGuard guard(s->device);
     const int rc = fetch_counts(s);
     if (rc != MIF_OK) return rc;
+    const int* c = s->h_counts + (size_t)frame * CNT_WORDS;
     for (int o = 0; o < kOctaves; o++) {
-        if (counts) counts[o] = s->h_counts[CNT_OCT0 + o];
-        if (raw_counts) raw_counts[o] = s->h_counts[CNT_RAW0 + o];
+        if (counts) counts[o] = c[CNT_OCT0 + o];
+        if (raw_counts) raw_counts[o] = c[CNT_RAW0 + o];
     }
-    return s->h_counts[CNT_STATUS];
+    return c[CNT_STATUS];
 }
 
 int mif_sift_extract(mif_sift* s, const uint8_t* pixels, float* keypoints, float* orientations,
@@ -933,7 +1060,7 @@ int mif_sift_extract(mif_sift* s, const uint8_t* pixels, float* keypoints, float
     const int want_desc = descriptors ? 1 : 0;
     for (int o = 0; o < kOctaves; o++) counts[o] = 0;
     MIF_HIP(hipMemcpyAsync(s->d_pixels, pixels, (size_t)s->W * s->H * s->C, hipMemcpyHostToDevice, s->stream));
-    int rc = enqueue_frame(s, s->d_pixels, want_desc);
+    int rc = enqueue_frames(s, s->d_pixels, 1, want_desc);
     if (rc != MIF_OK) return rc;
     rc = fetch_counts(s);
     if (rc != MIF_OK) return rc;
@@ -961,31 +1088,64 @@ int mif_sift_extract(mif_sift* s, const uint8_t* pixels, float* keypoints, float
     return MIF_OK;
 }
 
-int mif_sift_copy_level(mif_sift* s, int octave, int level, float* out)
+int mif_sift_copy_results(mif_sift* s, int frame, float* keypoints, float* orientations, float* descriptors,
+                          int capacity, int counts[MIF_SIFT_OCTAVES])
 {
-    if (!s || !out || octave < 0 || octave >= kOctaves || level < 0 || level >= kLevels) {
+    if (!s || !keypoints || !counts || frame < 0 || frame >= s->batch) {
+        mif::set_error("mif_sift_copy_results: bad argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(s->device);
+    const int rc = fetch_counts(s);
+    if (rc != MIF_OK) return rc;
+    const int* c = s->h_counts + (size_t)frame * CNT_WORDS;
+    for (int o = 0; o < kOctaves; o++) counts[o] = c[CNT_OCT0 + o];
+    const int total = c[CNT_TOTAL];
+    if (total > capacity) {
+        mif::set_error("mif_sift_copy_results: %d keypoints do not fit capacity %d", total, capacity);
+        return MIF_ERR_CAPACITY;
+    }
+    if (total > 0) {
+        const size_t off = (size_t)frame * s->cap;
+        MIF_HIP(hipMemcpy(keypoints, s->kp + off, (size_t)total * sizeof(float4), hipMemcpyDeviceToHost));
+        if (orientations)
+            MIF_HIP(hipMemcpy(orientations, s->orient + off, (size_t)total * sizeof(float), hipMemcpyDeviceToHost));
+        if (descriptors)
+            MIF_HIP(hipMemcpy(descriptors, s->desc + off * 128, (size_t)total * 128 * sizeof(float),
+                              hipMemcpyDeviceToHost));
+    }
+    return c[CNT_STATUS];
+}
+
+int mif_sift_copy_level(mif_sift* s, int frame, int octave, int level, float* out)
+{
+    if (!s || !out || frame < 0 || frame >= s->batch || octave < 0 || octave >= kOctaves || level < 0 ||
+        level >= kLevels) {
         mif::set_error("mif_sift_copy_level: bad argument");
         return MIF_ERR_INVALID_ARGUMENT;
     }
     mif::DeviceGuard guard(s->device);
     const OctaveBuf& O = s->oct[octave];
-    const size_t items = (size_t)O.w * O.h;
     MIF_HIP(hipStreamSynchronize(s->stream));
-    MIF_HIP(hipMemcpy(out, O.pyr + level * items, items * sizeof(float), hipMemcpyDeviceToHost));
+    if (O.items)
+        MIF_HIP(hipMemcpy(out, O.pyr + ((size_t)frame * kLevels + level) * O.items, O.items * sizeof(float),
+                          hipMemcpyDeviceToHost));
     return MIF_OK;
 }
 
-int mif_sift_copy_dog(mif_sift* s, int octave, int index, float* out)
+int mif_sift_copy_dog(mif_sift* s, int frame, int octave, int index, float* out)
 {
-    if (!s || !out || octave < 0 || octave >= kOctaves || index < 0 || index >= kLevels - 1) {
+    if (!s || !out || frame < 0 || frame >= s->batch || octave < 0 || octave >= kOctaves || index < 0 ||
+        index >= kLevels - 1) {
         mif::set_error("mif_sift_copy_dog: bad argument");
         return MIF_ERR_INVALID_ARGUMENT;
     }
     mif::DeviceGuard guard(s->device);
     const OctaveBuf& O = s->oct[octave];
-    const size_t items = (size_t)O.w * O.h;
     MIF_HIP(hipStreamSynchronize(s->stream));
-    MIF_HIP(hipMemcpy(out, O.dog + index * items, items * sizeof(float), hipMemcpyDeviceToHost));
+    if (O.items)
+        MIF_HIP(hipMemcpy(out, O.dog + ((size_t)frame * (kLevels - 1) + index) * O.items, O.items * sizeof(float),
+                          hipMemcpyDeviceToHost));
     return MIF_OK;
 }
 
@@ -995,6 +1155,36 @@ int mif_sift_taps(const mif_sift* s, int level, float* out, int capacity)
     const int n = (int)s->taps[level].size();
     for (int i = 0; i < n && i < capacity; i++) out[i] = s->taps[level][i];
     return s->fr[level];
+}
+
+int mif_sift_set_timing(mif_sift* s, int enable)
+{
+    if (!s) return MIF_ERR_INVALID_ARGUMENT;
+    mif::DeviceGuard guard(s->device);
+    if (enable && !s->ev_stage[0][0]) {
+        for (int o = 0; o < kOctaves; o++)
+            for (int i = 0; i <= MIF_SIFT_STAGES; i++) MIF_HIP(hipEventCreate(&s->ev_stage[o][i]));
+    }
+    s->timing = enable != 0;
+    return MIF_OK;
+}
+
+int mif_sift_stage_times(mif_sift* s, float ms[MIF_SIFT_OCTAVES][MIF_SIFT_STAGES])
+{
+    if (!s || !ms) return MIF_ERR_INVALID_ARGUMENT;
+    if (!s->timed_frame) {
+        mif::set_error("mif_sift_stage_times: no batch has been enqueued with timing enabled");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(s->device);
+    MIF_HIP(hipStreamSynchronize(s->stream));
+    for (int o = 0; o < kOctaves; o++)
+        for (int i = 0; i < MIF_SIFT_STAGES; i++) {
+            ms[o][i] = 0.0f;
+            if (s->oct[o].items == 0) continue;
+            MIF_HIP(hipEventElapsedTime(&ms[o][i], s->ev_stage[o][i], s->ev_stage[o][i + 1]));
+        }
+    return MIF_OK;
 }
 
 int mif_sift_last_elapsed_ms(mif_sift* s, float* ms)

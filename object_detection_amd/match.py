@@ -10,12 +10,13 @@ class Matcher:
     """Exact brute-force L2 two-nearest-neighbour search on the GPU (replaces the FLANN
     calls of common/kpmatch.h:174-176 and 284-286)."""
 
-    def __init__(self, max_query, max_database, device=0):
+    def __init__(self, max_query, max_database, device=0, max_pairs=1):
         self._lib = _lib.load_library()
         h = C.c_void_p()
-        _lib.check(self._lib.mif_match_create(device, max_query, max_database, C.byref(h)))
+        _lib.check(self._lib.mif_match_create_batched(device, max_query, max_database, max_pairs, C.byref(h)))
         self._h = h
         self.max_query, self.max_database, self.device = max_query, max_database, device
+        self.max_pairs = max_pairs
 
     def close(self):
         if getattr(self, "_h", None):
@@ -48,6 +49,19 @@ class Matcher:
             self._h, C.c_void_p(d_q), nq, C.c_void_p(d_nq) if d_nq else None, C.c_void_p(d_db), nd,
             C.c_void_p(d_nd) if d_nd else None, dim, ld, C.c_void_p(d_idx2), C.c_void_p(d_dist2),
             C.c_void_p(stream) if stream else None))
+
+
+    def top2_batch_device(self, pairs, nq, nd, dim, ld, filter_mode=0, stream=None):
+        """pairs: list of dicts with integer device addresses q, db, idx2, dist2 and optionally
+        nq, nd, good, summary, minmax (see mif_match_pair)."""
+        arr = (_lib.MatchPair * len(pairs))()
+        for a, p in zip(arr, pairs):
+            a.d_q, a.d_db = p["q"], p["db"]
+            a.d_nq, a.d_nd = p.get("nq"), p.get("nd")
+            a.d_idx2, a.d_dist2 = p["idx2"], p["dist2"]
+            a.d_good, a.d_summary, a.d_minmax = p.get("good"), p.get("summary"), p.get("minmax")
+        _lib.check(self._lib.mif_match_top2_batch_device(self._h, arr, len(pairs), nq, nd, dim, ld, filter_mode,
+                                                         C.c_void_p(stream) if stream else None))
 
 
 def pack_sift_rows(descriptors):

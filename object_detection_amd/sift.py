@@ -14,12 +14,14 @@ class SiftExtractor:
     """One GPU pipeline for images of a fixed geometry (the reference rebuilds its
     global sift_algorithm when the size changes, SIFT/sift.cpp:2161-2179)."""
 
-    def __init__(self, width, height, channels=1, device=0, up_scale=False):
+    def __init__(self, width, height, channels=1, device=0, up_scale=False, batch=1):
         self._lib = _lib.load_library()
         h = C.c_void_p()
-        _lib.check(self._lib.mif_sift_create(device, width, height, channels, 1 if up_scale else 0, C.byref(h)))
+        _lib.check(self._lib.mif_sift_create_batched(device, width, height, channels, 1 if up_scale else 0, batch,
+                                                     C.byref(h)))
         self._h = h
         self.width, self.height, self.channels, self.device = width, height, channels, device
+        self.batch = batch
         self.capacity = self._lib.mif_sift_capacity(self._h)
 
     def close(self):
@@ -63,9 +65,32 @@ class SiftExtractor:
         return rc, feats
 
     # --- device-resident path -------------------------------------------------
-    def enqueue(self, d_pixels_ptr, want_descriptors=True):
-        """d_pixels_ptr: integer device address of the frame's uint8 pixels."""
-        _lib.check(self._lib.mif_sift_enqueue(self._h, C.c_void_p(d_pixels_ptr), 1 if want_descriptors else 0))
+    def enqueue(self, d_pixels_ptr, nframes=1, want_descriptors=True):
+        """d_pixels_ptr: integer device address of nframes frames of uint8 pixels, back to back."""
+        _lib.check(self._lib.mif_sift_enqueue(self._h, C.c_void_p(d_pixels_ptr), nframes,
+                                              1 if want_descriptors else 0))
+
+    def wait_for(self, other):
+        """Work enqueued on this handle from now on waits for what `other` has enqueued so far."""
+        _lib.check(self._lib.mif_sift_wait_for(self._h, other._h))
+
+    def copy_results(self, frame=0, want_descriptors=True):
+        """Host copy of one frame of the last enqueued batch -> (status, SiftFeatures)."""
+        cap = max(self.capacity, 1)
+        kp = np.empty((cap, 4), np.float32)
+        ori = np.empty(cap, np.float32) if want_descriptors else None
+        des = np.empty((cap, 128), np.float32) if want_descriptors else None
+        counts = (C.c_int * 3)()
+        rc = self._lib.mif_sift_copy_results(self._h, frame, kp.ctypes.data,
+                                             ori.ctypes.data if want_descriptors else None,
+                                             des.ctypes.data if want_descriptors else None, cap, counts)
+        _lib.check(rc, allow=(_lib.MIF_ERR_NO_KEYPOINTS,))
+        cnt = [counts[0], counts[1], counts[2]]
+        n = sum(cnt)
+        octs = np.repeat(np.arange(3, dtype=np.int32), cnt)
+        return rc, SiftFeatures(kp[:n].copy(), octs,
+                                ori[:n].copy() if want_descriptors else np.zeros(0, np.float32),
+                                des[:n].copy() if want_descriptors else np.zeros((0, 128), np.float32), cnt, 0.0)
 
     def sync(self):
         _lib.check(self._lib.mif_sift_sync(self._h))
@@ -78,12 +103,22 @@ class SiftExtractor:
         _lib.check(self._lib.mif_sift_device_results(self._h, C.byref(kp), C.byref(ori), C.byref(des), C.byref(cnt)))
         return kp.value, ori.value, des.value, cnt.value
 
-    def read_counts(self):
+    def read_counts(self, frame=0):
         c, r = (C.c_int * 3)(), (C.c_int * 3)()
-        status = self._lib.mif_sift_read_counts(self._h, c, r)
+        status = self._lib.mif_sift_read_counts(self._h, frame, c, r)
         if status not in (0, _lib.MIF_ERR_NO_KEYPOINTS):
             _lib.check(status)
         return status, list(c), list(r)
+
+    def set_timing(self, enable=True):
+        _lib.check(self._lib.mif_sift_set_timing(self._h, 1 if enable else 0))
+
+    def stage_times(self):
+        """ms per [octave][stage] of the last batch enqueued with timing on; stages: base image,
+        scale space (6 blur launches), detector, orientation + descriptor."""
+        buf = (C.c_float * 12)()
+        _lib.check(self._lib.mif_sift_stage_times(self._h, buf))
+        return np.array(buf[:], dtype=np.float32).reshape(3, 4)
 
     def last_elapsed_ms(self):
         ms = C.c_float()
@@ -91,16 +126,16 @@ class SiftExtractor:
         return ms.value
 
     # --- probes (SIFT/sift.h:13-21 get_blur / get_diff_blur) --------------------
-    def level(self, octave, level):
+    def level(self, octave, level, frame=0):
         w, h, _ = self.octave_info(octave)
         out = np.empty((h, w), np.float32)
-        _lib.check(self._lib.mif_sift_copy_level(self._h, octave, level, out.ctypes.data))
+        _lib.check(self._lib.mif_sift_copy_level(self._h, frame, octave, level, out.ctypes.data))
         return out
 
-    def dog(self, octave, index):
+    def dog(self, octave, index, frame=0):
         w, h, _ = self.octave_info(octave)
         out = np.empty((h, w), np.float32)
-        _lib.check(self._lib.mif_sift_copy_dog(self._h, octave, index, out.ctypes.data))
+        _lib.check(self._lib.mif_sift_copy_dog(self._h, frame, octave, index, out.ctypes.data))
         return out
 
     def taps(self, level):

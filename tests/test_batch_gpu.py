@@ -1,0 +1,105 @@
+"""GPU parity of the batched, device-resident path (what bench.py runs): a batch of frames through
+mif_sift_enqueue, then frame-to-previous-frame matching with the SIFT good-match filter on the device."""
+import numpy as np
+import pytest
+
+import object_detection_amd as oda
+from object_detection_amd import _lib
+import oracle_lib as orc
+from synth import blob_image, dense_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames():
+    return [blob_image(256, 192, seed=1), blob_image(256, 192, seed=1, shift=(3, 2)),
+            dense_image(256, 192, 0), np.full((192, 256), 90, np.uint8), blob_image(256, 192, seed=9)]
+
+
+def test_batched_extract_and_match_against_checker():
+    import torch
+    frames = _frames()
+    B = len(frames)
+    dev = torch.device("cuda:0")
+    px = torch.from_numpy(np.stack(frames)).to(dev)
+    ex = oda.SiftExtractor(256, 192, 1, batch=B)
+    ex.set_timing(True)
+    ex.enqueue(px.data_ptr(), B)
+    kp_p, ori_p, des_p, cnt_p = ex.device_results()
+    cap = ex.capacity
+    oracle = []
+    for f, img in enumerate(frames):
+        S = orc.SiftOracle(256, 192)
+        rc_o = S.run(img)
+        rc_g, feat = ex.copy_results(f)
+        assert rc_g == rc_o, f
+        if rc_o == 0:
+            kp, octs, ori, des = S.all_features()
+            assert feat.counts == [S.count(o) for o in range(3)]
+            assert np.array_equal(feat.keypoints.view(np.uint32), kp.view(np.uint32))
+            assert np.array_equal(feat.orientations.view(np.uint32), ori.view(np.uint32))
+            assert np.array_equal(feat.descriptors.view(np.uint32), des.view(np.uint32))
+            oracle.append(des)
+        else:
+            assert feat.counts == [0, 0, 0]
+            oracle.append(np.zeros((0, 128), np.float32))
+    t = ex.stage_times()
+    assert t.shape == (3, 4) and np.all(t >= 0) and t.sum() > 0
+
+    # frame b against frame b-1 with device-side row counts, shifted rows (dim 127 of ld 128) and the SIFT filter
+    idx = torch.full((B, cap, 2), -7, dtype=torch.int32, device=dev)
+    dist = torch.zeros((B, cap, 2), dtype=torch.float32, device=dev)
+    good = torch.zeros((B, cap), dtype=torch.uint8, device=dev)
+    summ = torch.full((B, 2), -1, dtype=torch.int32, device=dev)
+    mnmx = torch.zeros((B, 2), dtype=torch.float32, device=dev)
+    m = oda.Matcher(cap, cap, max_pairs=B)
+    pairs = []
+    for b in range(1, B):
+        pairs.append(dict(q=des_p + b * cap * 512, db=des_p + (b - 1) * cap * 512,
+                          nq=cnt_p + b * 32 + 12, nd=cnt_p + (b - 1) * 32 + 12,
+                          idx2=idx[b].data_ptr(), dist2=dist[b].data_ptr(), good=good[b].data_ptr(),
+                          summary=summ[b].data_ptr(), minmax=mnmx[b].data_ptr()))
+    m.top2_batch_device(pairs, cap, cap, 127, 128, _lib.FILTER_SIFT, stream=ex.stream())
+    ex.sync()
+    idx, dist, good, summ, mnmx = idx.cpu().numpy(), dist.cpu().numpy(), good.cpu().numpy(), summ.cpu().numpy(), mnmx.cpu().numpy()
+    for b in range(1, B):
+        q, db = oracle[b], oracle[b - 1]
+        nq = len(q)
+        assert summ[b, 1] == nq
+        if nq == 0:
+            assert summ[b, 0] == 0
+            continue
+        i_o, d_o = orc.match_top2(oda.pack_sift_rows(q), oda.pack_sift_rows(db))
+        assert np.array_equal(idx[b, :nq], i_o)
+        assert np.array_equal(dist[b, :nq].view(np.uint32), d_o.view(np.uint32))
+        mn = min(100.0, float(d_o[:, 0].astype(np.float64).min()))
+        keep = d_o[:, 0].astype(np.float64) <= max(2.5 * mn, 0.35)
+        assert np.array_equal(good[b, :nq].astype(bool), keep)
+        assert summ[b, 0] == int(keep.sum())
+        assert mnmx[b, 0] == np.float32(mn)
+
+
+def test_ratio_filter_on_device():
+    import torch
+    from synth import sift_like_descriptors
+    dev = torch.device("cuda:0")
+    a = sift_like_descriptors(300, 6)
+    b = sift_like_descriptors(500, 7)
+    rng = np.random.RandomState(8)
+    b[:150] = np.clip(a[:150] + rng.normal(0, 4, (150, 128)), 0, 255).astype(np.float32)
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    idx = torch.zeros((300, 2), dtype=torch.int32, device=dev)
+    dist = torch.zeros((300, 2), dtype=torch.float32, device=dev)
+    good = torch.zeros(300, dtype=torch.uint8, device=dev)
+    summ = torch.zeros(2, dtype=torch.int32, device=dev)
+    m = oda.Matcher(300, 500)
+    m.top2_batch_device([dict(q=ta.data_ptr(), db=tb.data_ptr(), idx2=idx.data_ptr(), dist2=dist.data_ptr(),
+                              good=good.data_ptr(), summary=summ.data_ptr())], 300, 500, 128, 128,
+                        _lib.FILTER_RATIO)
+    torch.cuda.synchronize()
+    i_o, d_o = orc.match_top2(a, b)
+    keep = d_o[:, 0] < np.float32(0.75) * d_o[:, 1]
+    assert np.array_equal(idx.cpu().numpy(), i_o)
+    assert np.array_equal(good.cpu().numpy().astype(bool), keep)
+    assert summ.cpu().numpy().tolist() == [int(keep.sum()), 300]
+    assert keep.sum() >= 140
