@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""1080p SIFT extract + match throughput on MI355X (the metric of BASELINE.json).
+
+A step = one batch of `--batch` synthetic 1920x1080 BGR frames, already resident
+in HBM, through the whole hot path: gray conversion, 3-octave scale space + DoG,
+detection, orientation, 128-d descriptors, then brute-force matching of every
+frame against the previous frame (frame 0 of a batch against the last frame of
+the previous batch) with the reference's SIFT good-match rule. Frames are
+independent, so ranks process different frames with no data-path collective
+(weak scaling); value = all ranks' frames / max-over-ranks time.
+
+python bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
+# Algorithmic bytes of the scale-space stage per pixel and octave: horizontal blur 6 x (r4 + w4),
+# vertical blur 6 x (r4 + w4), DoG fused into the vertical pass 5 x (r4 + w4) = 136 B, spread over the
+# six blur_level launches of an octave (22.67 B per pixel and launch).
+ALG_BYTES_PER_PX_OCTAVE = 136.0
+# What the fused blur_level kernel has to move at least: level 0 r4 + w4, levels 1-5 r4 + w4 + w4 (DoG).
+MIN_BYTES_PER_PX_OCTAVE = 68.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def make_frames(width, height, batch, rank):
+    from synth import blob_image
+    frames = [blob_image(width, height, seed=1234 + 100 * rank, channels=3, shift=(2 * t, t)) for t in range(batch)]
+    return np.stack(frames)
+
+
+class Pipeline:
+    """Two batched SIFT handles used alternately (so the previous batch's last frame is still in
+    HBM when the next batch is matched against it) and one batched matcher per handle."""
+
+    def __init__(self, oda, torch, dev_index, width, height, batch):
+        self.oda, self.torch, self.B = oda, torch, batch
+        self.dev = torch.device("cuda", dev_index)
+        self.h = [oda.SiftExtractor(width, height, 3, device=dev_index, batch=batch) for _ in range(2)]
+        self.cap = self.h[0].capacity
+        self.m = [oda.Matcher(self.cap, self.cap, device=dev_index, max_pairs=batch) for _ in range(2)]
+        B, cap = batch, self.cap
+        self.idx = [torch.zeros((B, cap, 2), dtype=torch.int32, device=self.dev) for _ in range(2)]
+        self.dist = [torch.zeros((B, cap, 2), dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self.good = [torch.zeros((B, cap), dtype=torch.uint8, device=self.dev) for _ in range(2)]
+        self.summ = [torch.zeros((B, 2), dtype=torch.int32, device=self.dev) for _ in range(2)]
+        self.res = [h.device_results() for h in self.h]
+        self.pairs = [self._pairs(k) for k in range(2)]
+        self.step_no = 0
+
+    def _pairs(self, k):
+        B, cap = self.B, self.cap
+        _, _, des, cnt = self.res[k]
+        _, _, pdes, pcnt = self.res[1 - k]
+        out = []
+        for b in range(B):
+            if b == 0:
+                db, nd = pdes + (B - 1) * cap * 512, pcnt + (B - 1) * 32 + 12
+            else:
+                db, nd = des + (b - 1) * cap * 512, cnt + (b - 1) * 32 + 12
+            out.append(dict(q=des + b * cap * 512, db=db, nq=cnt + b * 32 + 12, nd=nd,
+                            idx2=self.idx[k][b].data_ptr(), dist2=self.dist[k][b].data_ptr(),
+                            good=self.good[k][b].data_ptr(), summary=self.summ[k][b].data_ptr()))
+        return out
+
+    def step(self, frames_ptr):
+        from object_detection_amd import _lib
+        k = self.step_no & 1
+        h, other = self.h[k], self.h[1 - k]
+        # the other handle's stream holds the previous batch: its descriptors feed pair 0, and its
+        # matcher still reads this handle's old results
+        h.wait_for(other)
+        h.enqueue(frames_ptr, self.B, True)
+        self.m[k].top2_batch_device(self.pairs[k], self.cap, self.cap, 127, 128, _lib.FILTER_SIFT, stream=h.stream())
+        self.step_no += 1
+
+    def sync(self):
+        for h in self.h:
+            h.sync()
+
+
+def cpu_baseline(frames, budget_s):
+    """CPU restatement of the reference's -f 0 path (oracle/, OpenMP) on a bounded sample of the same
+    frames: extraction of every sampled frame plus matching against the previous sampled frame."""
+    import oracle_lib as orc
+    import object_detection_amd as oda
+    n, h, w, _ = frames.shape
+    S = orc.SiftOracle(w, h, 3)
+    prev = None
+    done, t0 = 0, time.perf_counter()
+    while done < max(2, min(n, 64)):
+        S.run(frames[done % n])
+        des = S.all_features()[3]
+        if prev is not None and len(des) and len(prev):
+            idx, dist = orc.match_top2(oda.pack_sift_rows(des), oda.pack_sift_rows(prev))
+            mn = min(100.0, float(dist[:, 0].min()))
+            _ = dist[:, 0] <= max(2.5 * mn, 0.35)
+        prev = des
+        done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "frames/s", "cores": orc.lib().orc_get_threads(), "kind": "port",
+            "sample": "%d frames %dx%d BGR, extract + match vs previous frame, OpenMP restatement of the "
+                      "reference -f 0 path (oracle/)" % (done, w, h)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import object_detection_amd as oda
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    frames_np = make_frames(args.width, args.height, args.batch, rank)
+    frames = torch.from_numpy(frames_np).to(torch.device("cuda", local_rank))
+    pipe = Pipeline(oda, torch, local_rank, args.width, args.height, args.batch)
+
+    for _ in range(args.warmup):
+        pipe.step(frames.data_ptr())
+    pipe.sync()
+    for h in pipe.h:
+        h.set_timing(True)
+
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.step(frames.data_ptr())
+    pipe.sync()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    t = torch.tensor([dt], dtype=torch.float64, device=frames.device)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    # stage times of the last two batches of the timed region (one per handle), measured with HIP events on
+    # the handles' own streams; blur_level is the dominant bandwidth kernel (6 launches per octave)
+    stage = np.mean([h.stage_times() for h in pipe.h], axis=0)            # ms [octave][stage]
+    px = [h_ * w_ for (w_, h_, _) in (pipe.h[0].octave_info(o) for o in range(3))]
+    blur_ms = float(stage[:, 1].sum())
+    alg_bytes = ALG_BYTES_PER_PX_OCTAVE * sum(px) * args.batch
+    achieved = alg_bytes / (blur_ms * 1e-3) / 1e9
+    launches = 18
+    summ = pipe.summ[(pipe.step_no - 1) & 1].cpu().numpy()
+    counts = pipe.h[(pipe.step_no - 1) & 1].read_counts(args.batch - 1)
+
+    if rank == 0:
+        frames_total = args.batch * args.steps * world
+        out = {
+            "metric": "1080p SIFT extract+match frames/sec",
+            "value": frames_total / dt_max,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "SIFT extract + match-vs-previous-frame on a synthetic %dx%d BGR sequence "
+                                   "(stand-in for basketball.mp4, BASELINE.json configs[2])" % (args.width, args.height),
+                       "frames_per_step": args.batch, "octaves": 3, "levels": 6,
+                       "keypoints_last_frame": counts[1], "good_matches_last_frame": int(summ[-1, 0]),
+                       "parallelism": "frames sharded over %d GPU(s), no collective" % world},
+            "roofline": {
+                "bound": "hbm", "kernel": "k_blur_level (H+V+DoG fused, 18 launches per batch)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_us": blur_ms * 1e3 / launches,
+                "alg_bytes_per_launch": alg_bytes / launches,
+                "achieved_min_traffic": achieved * MIN_BYTES_PER_PX_OCTAVE / ALG_BYTES_PER_PX_OCTAVE,
+            },
+            "stage_ms_per_batch": {"base": float(stage[:, 0].sum()), "scale_space": blur_ms,
+                                   "detector": float(stage[:, 2].sum()), "orient_desc": float(stage[:, 3].sum())},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
