@@ -138,15 +138,29 @@ __global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ sr
     const int x0 = blockIdx.x * TW;
     const int y0 = blockIdx.y * TH;
 
-    // stage the input window, zero outside the image
-    for (int idx = tid; idx < EW * EH; idx += 256) {
-        const int ly = idx / EW;
-        const int lx = idx - ly * EW;
-        const int gx = x0 - FR + lx;
-        const int gy = y0 - FR + ly;
-        float v = 0.0f;
-        if (gx >= 0 && gx < w && gy >= 0 && gy < h) v = src[(size_t)gy * w + gx];
-        s_in[lx * PT + ly] = v;
+    // stage the input window, zero outside the image; all loads of a thread are
+    // issued before the first LDS store waits for one
+    {
+        constexpr int kIters = (EW * EH + 255) / 256;
+        float stage[kIters];
+#pragma unroll
+        for (int it = 0; it < kIters; it++) {
+            const int idx = tid + it * 256;
+            const int ly = idx / EW;
+            const int lx = idx - ly * EW;
+            const int gx = x0 - FR + lx;
+            const int gy = y0 - FR + ly;
+            float v = 0.0f;
+            if (idx < EW * EH && gx >= 0 && gx < w && gy >= 0 && gy < h) v = src[(size_t)gy * w + gx];
+            stage[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < kIters; it++) {
+            const int idx = tid + it * 256;
+            const int ly = idx / EW;
+            const int lx = idx - ly * EW;
+            if (idx < EW * EH) s_in[lx * PT + ly] = stage[it];
+        }
     }
     __syncthreads();
 
@@ -207,110 +221,265 @@ __device__ __forceinline__ bool loc_extremum(float v, const float* __restrict__ 
 #undef CMP
 }
 
-// sift.cpp:265-417 kDetector for the pixel (x, y) of DoG level s in octave o.
-// Returns true when the reference would append a feature; *out is that feature.
-// The refinement steps tx, ty, ts but keeps reading the same three DoG images,
-// as the reference does.
-__device__ bool detect_pixel(const float* __restrict__ dp, const float* __restrict__ dc,
-                             const float* __restrict__ dn, int w, int h, int s, int o, int x, int y, float4* out)
+// The 19 DoG samples one Newton step reads around (tx, ty): the 3x3 of the
+// current image and the plus-shaped neighbourhoods of the previous and next one.
+struct Stencil {
+    float c00, cxp, cxm, cyp, cym;        // current: centre, x+1, x-1, y+1, y-1
+    float cpp, cmm, cpm, cmp;             // current: (y+1,x+1), (y-1,x-1), (y+1,x-1), (y-1,x+1)
+    float n00, nxp, nxm, nyp, nym;        // next image
+    float p00, pxp, pxm, pyp, pym;        // previous image
+};
+
+struct NewtonStep {
+    float Dxx, Dyy, Dxy, gx, gy, gz, ox, oy, oz;
+    bool singular;
+};
+
+// One iteration of the sub-pixel fit, sift.cpp:339-377: gradient, 3x3 Hessian,
+// its adjugate scaled by -1/det, offset = -H^-1 grad. Every operation rounds
+// separately in the order written there.
+__device__ __forceinline__ NewtonStep newton_step(const Stencil& t)
 {
-    if (y <= kBorder || y >= h - kBorder || x <= kBorder || x >= w - kBorder) return false;
-    float cur = dc[y * w + x];
-    if ((double)mif_fabsf(cur) <= K_CONTR_THR_1) return false;
-    if (!(loc_extremum<true>(cur, dp, dc, dn, w, y, x) || loc_extremum<false>(cur, dp, dc, dn, w, y, x)))
-        return false;
+    NewtonStep r;
+    r.gx = 0.5f * (t.cxp - t.cxm);
+    r.gy = 0.5f * (t.cyp - t.cym);
+    r.gz = 0.5f * (t.n00 - t.p00);
+    r.Dxx = t.cxp - 2.0f * t.c00 + t.cxm;
+    r.Dyy = t.cyp - 2.0f * t.c00 + t.cym;
+    const float Dss = t.n00 - 2.0f * t.c00 + t.p00;
+    r.Dxy = 0.25f * (t.cpp + t.cmm - t.cpm - t.cmp);
+    const float Dxs = 0.25f * (t.nxp + t.pxm - t.nxm - t.pxp);
+    const float Dys = 0.25f * (t.nyp + t.pym - t.pyp - t.nym);
+    const float Dxx = r.Dxx, Dyy = r.Dyy, Dxy = r.Dxy;
+    // adjugate of the 3x3 Hessian, rows as in sift.cpp:356-366
+    float a0 = Dyy * Dss - Dys * Dys;
+    float b0 = Dys * Dxs - Dxy * Dss;
+    float c0 = Dxy * Dys - Dyy * Dxs;
+    const float det = Dxx * a0 + Dxy * b0 + Dxs * c0;
+    float a1 = Dxs * Dys - Dxy * Dss;
+    float a2 = Dxy * Dys - Dxs * Dyy;
+    float b1 = Dxx * Dss - Dxs * Dxs;
+    float b2 = Dxs * Dxy - Dxx * Dys;
+    float c1 = Dxy * Dxs - Dxx * Dys;
+    float c2 = Dxx * Dyy - Dxy * Dxy;
+    r.singular = (det == 0.0f);
+    const float dv = -1.0f / det;
+    a0 *= dv; a1 *= dv; a2 *= dv;
+    b0 *= dv; b1 *= dv; b2 *= dv;
+    c0 *= dv; c1 *= dv; c2 *= dv;
+    r.ox = a0 * r.gx + a1 * r.gy + a2 * r.gz;
+    r.oy = b0 * r.gx + b1 * r.gy + b2 * r.gz;
+    r.oz = c0 * r.gx + c1 * r.gy + c2 * r.gz;
+    return r;
+}
 
-    float Dxx = 0.f, Dyy = 0.f, Dxy = 0.f;
-    float gx = 0.f, gy = 0.f, gz = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
-    int tx = x, ty = y, ts = s, iter;
-    for (iter = 0; iter < kInterpSteps; iter++) {
-        const float c00 = dc[ty * w + tx];
-        const float cxp = dc[ty * w + tx + 1], cxm = dc[ty * w + tx - 1];
-        const float cyp = dc[(ty + 1) * w + tx], cym = dc[(ty - 1) * w + tx];
-        const float n00 = dn[ty * w + tx], p00 = dp[ty * w + tx];
-        gx = 0.5f * (cxp - cxm);
-        gy = 0.5f * (cyp - cym);
-        gz = 0.5f * (n00 - p00);
-        Dxx = cxp - 2.0f * c00 + cxm;
-        Dyy = cyp - 2.0f * c00 + cym;
-        const float Dss = n00 - 2.0f * c00 + p00;
-        Dxy = 0.25f * (dc[(ty + 1) * w + tx + 1] + dc[(ty - 1) * w + tx - 1] - dc[(ty + 1) * w + tx - 1] -
-                       dc[(ty - 1) * w + tx + 1]);
-        const float Dxs = 0.25f * (dn[ty * w + tx + 1] + dp[ty * w + tx - 1] - dn[ty * w + tx - 1] -
-                                   dp[ty * w + tx + 1]);
-        const float Dys = 0.25f * (dn[(ty + 1) * w + tx] + dp[(ty - 1) * w + tx] - dp[(ty + 1) * w + tx] -
-                                   dn[(ty - 1) * w + tx]);
-        // adjugate of the 3x3 Hessian, rows as in sift.cpp:356-366
-        float a0 = Dyy * Dss - Dys * Dys;
-        float b0 = Dys * Dxs - Dxy * Dss;
-        float c0 = Dxy * Dys - Dyy * Dxs;
-        const float det = Dxx * a0 + Dxy * b0 + Dxs * c0;
-        float a1 = Dxs * Dys - Dxy * Dss;
-        float a2 = Dxy * Dys - Dxs * Dyy;
-        float b1 = Dxx * Dss - Dxs * Dxs;
-        float b2 = Dxs * Dxy - Dxx * Dys;
-        float c1 = Dxy * Dxs - Dxx * Dys;
-        float c2 = Dxx * Dyy - Dxy * Dxy;
-        if (det == 0.0f) return false;
-        const float dv = -1.0f / det;
-        a0 *= dv; a1 *= dv; a2 *= dv;
-        b0 *= dv; b1 *= dv; b2 *= dv;
-        c0 *= dv; c1 *= dv; c2 *= dv;
-        ox = a0 * gx + a1 * gy + a2 * gz;
-        oy = b0 * gx + b1 * gy + b2 * gz;
-        oz = c0 * gx + c1 * gy + c2 * gz;
-        if (mif_fabsf(ox) < 0.5f && mif_fabsf(oy) < 0.5f && mif_fabsf(oz) < 0.5f) break;
-        tx += (int)mif_roundf(ox);
-        if (tx < kBorder || tx >= w - kBorder) return false;
-        ty += (int)mif_roundf(oy);
-        if (ty < kBorder || ty >= h - kBorder) return false;
-        ts += (int)mif_roundf(oz);
-        if (ts < 1 || ts > kIntervals) return false;
-    }
-    if (iter >= kInterpSteps) return false;
+__device__ __forceinline__ bool step_converged(const NewtonStep& r)
+{
+    return mif_fabsf(r.ox) < 0.5f && mif_fabsf(r.oy) < 0.5f && mif_fabsf(r.oz) < 0.5f;
+}
 
-    const float trH = Dxx + Dyy;
-    const float detH = Dxx * Dyy - Dxy * Dxy;
+// sift.cpp:393-415: edge test, contrast test and the feature record, given the
+// converged step at (tx, ty, ts) and `cur`, the DoG sample the reference picks
+// there (previous / current / next image for ts = 1 / 2 / other).
+__device__ __forceinline__ bool finish_pixel(const NewtonStep& r, float cur, int tx, int ty, int ts, int o, float4* out)
+{
+    const float trH = r.Dxx + r.Dyy;
+    const float detH = r.Dxx * r.Dyy - r.Dxy * r.Dxy;
     if ((double)mif_fabsf(detH) <= 1e-8) return false;
     if ((trH * trH) / detH >= 12.0f) return false;    // (10+1)*(10+1)/10 in integers, sift.cpp:398
-
-    cur = ts == 1 ? dp[ty * w + tx] : ts == 2 ? dc[ty * w + tx] : dn[ty * w + tx];   // sift.cpp:400
-    const float contrast = cur + 0.5f * (gx * ox + gy * oy + gz * oz);
+    const float contrast = cur + 0.5f * (r.gx * r.ox + r.gy * r.oy + r.gz * r.oz);
     if (!(mif_fabsf(contrast) > (float)(K_CONTR_THR / kIntervals))) return false;
-
     const float p2o = mif_pow2i(o);
-    out->x = ((float)tx + ox) * p2o;
-    out->y = ((float)ty + oy) * p2o;
-    out->z = (float)(K_SIGMA * (double)mif_exp2f(((float)ts + oz) / (float)kIntervals));
+    out->x = ((float)tx + r.ox) * p2o;
+    out->y = ((float)ty + r.oy) * p2o;
+    out->z = (float)(K_SIGMA * (double)mif_exp2f(((float)ts + r.oz) / (float)kIntervals));
     out->w = (float)ts;
     return true;
 }
 
-// Detection pass: grid (ceil(w/256), h, 3 levels x frames), 256 threads. Every
-// wave tests 64 consecutive pixels of one row and stores its ballot as one
-// 64-bit word of the acceptance bitmask; row totals are accumulated with
-// integer atomics (order independent).
+// sift.cpp:323-417, the part of kDetector that follows the extremum test, for
+// the pixel (x, y) of DoG level s in octave o: sub-pixel refinement, edge and
+// contrast tests. Returns true when the reference would append a feature; *out
+// is that feature. The refinement steps tx, ty, ts but keeps reading the same
+// three DoG images, as the reference does.
+__device__ bool refine_pixel(const float* __restrict__ dp, const float* __restrict__ dc,
+                             const float* __restrict__ dn, int w, int h, int s, int o, int x, int y, float4* out)
+{
+    NewtonStep r;
+    int tx = x, ty = y, ts = s, iter;
+    for (iter = 0; iter < kInterpSteps; iter++) {
+        const int i0 = ty * w + tx;
+        Stencil t;
+        t.c00 = dc[i0]; t.cxp = dc[i0 + 1]; t.cxm = dc[i0 - 1]; t.cyp = dc[i0 + w]; t.cym = dc[i0 - w];
+        t.cpp = dc[i0 + w + 1]; t.cmm = dc[i0 - w - 1]; t.cpm = dc[i0 + w - 1]; t.cmp = dc[i0 - w + 1];
+        t.n00 = dn[i0]; t.nxp = dn[i0 + 1]; t.nxm = dn[i0 - 1]; t.nyp = dn[i0 + w]; t.nym = dn[i0 - w];
+        t.p00 = dp[i0]; t.pxp = dp[i0 + 1]; t.pxm = dp[i0 - 1]; t.pyp = dp[i0 + w]; t.pym = dp[i0 - w];
+        r = newton_step(t);
+        if (r.singular) return false;
+        if (step_converged(r)) break;
+        tx += (int)mif_roundf(r.ox);
+        if (tx < kBorder || tx >= w - kBorder) return false;
+        ty += (int)mif_roundf(r.oy);
+        if (ty < kBorder || ty >= h - kBorder) return false;
+        ts += (int)mif_roundf(r.oz);
+        if (ts < 1 || ts > kIntervals) return false;
+    }
+    if (iter >= kInterpSteps) return false;
+    const float cur = ts == 1 ? dp[ty * w + tx] : ts == 2 ? dc[ty * w + tx] : dn[ty * w + tx];   // sift.cpp:400
+    return finish_pixel(r, cur, tx, ty, ts, o, out);
+}
+
+// Detection pass (sift.cpp:276-322, then the refinement). A block of 256
+// threads owns a 64 x 16 pixel tile of one frame.
+//  A. The five DoG images of the tile plus a one-pixel halo are staged in LDS
+//     (20 B read per pixel for all three detector levels).
+//  B. Every wave walks four consecutive rows, 64 pixels at a time, and tests
+//     border, |D| > 0.0108333 and the 3x3x3 extremum without branches; the few
+//     survivors are queued in LDS.
+//  C. The queue is dealt to the threads, one candidate each: first Newton step
+//     from the LDS tile, further steps (rare) from global memory; accepted
+//     candidates set their bit in the tile's acceptance bitmask.
+//  D. The tile's 3 x 16 bitmask words go to global memory and the row totals
+//     are accumulated with integer atomics (order independent).
+constexpr int kDetTW = 64, kDetTH = 16, kDetPitch = kDetTW + 2;
+
 __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ dog, size_t dog_stride,
                                                 unsigned long long* __restrict__ mask, int* __restrict__ rowcnt,
                                                 int w, int h, int words, int o)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
-    const int f = blockIdx.z / kIntervals;
-    const int s = blockIdx.z - f * kIntervals + 1;
+    constexpr int kTile = (kDetTH + 2) * kDetPitch;
+    __shared__ float s_d[kLevels - 1][kTile];
+    __shared__ int s_queue[kIntervals * kDetTW * kDetTH];
+    __shared__ unsigned long long s_mask[kIntervals][kDetTH];
+    __shared__ int s_ncand;
+    const int f = blockIdx.z;
+    const int x0 = blockIdx.x * kDetTW, y0 = blockIdx.y * kDetTH;
     const size_t items = (size_t)w * h;
     dog += (size_t)f * dog_stride;
-    bool found = false;
-    if (x < w) {
-        float4 kp;
-        found = detect_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o, x, y, &kp);
+    if (threadIdx.x == 0) s_ncand = 0;
+    if (threadIdx.x < kIntervals * kDetTH) s_mask[threadIdx.x / kDetTH][threadIdx.x % kDetTH] = 0ull;
+    {
+        // all loads of a thread are issued before the first LDS store waits for one
+        constexpr int kIters = ((kLevels - 1) * kTile + 255) / 256;
+        float stage[kIters];
+#pragma unroll
+        for (int it = 0; it < kIters; it++) {
+            const int idx = threadIdx.x + it * 256;
+            const int l = idx / kTile;
+            const int rem = idx - l * kTile;
+            const int ly = rem / kDetPitch;
+            const int lx = rem - ly * kDetPitch;
+            const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+            float v = 0.0f;
+            if (idx < (kLevels - 1) * kTile && gx >= 0 && gx < w && gy >= 0 && gy < h)
+                v = dog[l * items + (size_t)gy * w + gx];
+            stage[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < kIters; it++) {
+            const int idx = threadIdx.x + it * 256;
+            if (idx < (kLevels - 1) * kTile) (&s_d[0][0])[idx] = stage[it];
+        }
     }
-    const unsigned long long m = __ballot(found);
-    const int word = x >> 6;                      // uniform over the wave
-    if ((threadIdx.x & 63) == 0 && word < words) {
-        const size_t r = (size_t)f * kIntervals * h + (s - 1) * h + y;
-        mask[r * words + word] = m;
-        if (m) atomicAdd(&rowcnt[r], __popcll(m));
+    __syncthreads();
+    // B. Per DoG image a lane keeps the 3x3 neighbourhood of its pixel in
+    // registers and slides it down one row at a time (3 LDS reads per image and
+    // row). "v > every neighbour" is evaluated as v > max(neighbours): maxP
+    // leaves out (y-1, x+1) -- the position the reference's test of the previous
+    // image never looks at (sift.cpp:299-301) -- maxC leaves out the centre, max9
+    // takes all nine; likewise for minima.
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int x = x0 + lane;
+    constexpr int kRowsPerWave = kDetTH / 4;
+    float nb[kLevels - 1][3][3];
+#pragma unroll
+    for (int l = 0; l < kLevels - 1; l++)
+#pragma unroll
+        for (int r = 1; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) nb[l][r][c] = s_d[l][(wave * kRowsPerWave + r - 1) * kDetPitch + lane + c];
+#pragma unroll
+    for (int rr = 0; rr < kRowsPerWave; rr++) {
+        const int ly = wave * kRowsPerWave + rr;
+        const int y = y0 + ly;
+        float maxP[3], minP[3], maxC[3], minC[3], max9[3], min9[3], cen[3];
+#pragma unroll
+        for (int l = 0; l < kLevels - 1; l++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                nb[l][0][c] = nb[l][1][c];
+                nb[l][1][c] = nb[l][2][c];
+                nb[l][2][c] = s_d[l][(ly + 2) * kDetPitch + lane + c];
+            }
+            const float (*v)[3] = nb[l];
+            const float rmx0 = fmaxf(fmaxf(v[0][0], v[0][1]), v[0][2]), rmn0 = fminf(fminf(v[0][0], v[0][1]), v[0][2]);
+            const float rmx1 = fmaxf(fmaxf(v[1][0], v[1][1]), v[1][2]), rmn1 = fminf(fminf(v[1][0], v[1][1]), v[1][2]);
+            const float rmx2 = fmaxf(fmaxf(v[2][0], v[2][1]), v[2][2]), rmn2 = fminf(fminf(v[2][0], v[2][1]), v[2][2]);
+            if (l <= 2) {           // previous image of level l + 1
+                maxP[l] = fmaxf(fmaxf(fmaxf(v[0][0], v[0][1]), rmx1), rmx2);
+                minP[l] = fminf(fminf(fminf(v[0][0], v[0][1]), rmn1), rmn2);
+            }
+            if (l >= 1 && l <= 3) { // current image of level l
+                maxC[l - 1] = fmaxf(fmaxf(rmx0, fmaxf(v[1][0], v[1][2])), rmx2);
+                minC[l - 1] = fminf(fminf(rmn0, fminf(v[1][0], v[1][2])), rmn2);
+                cen[l - 1] = v[1][1];
+            }
+            if (l >= 2) {           // next image of level l - 1
+                max9[l - 2] = fmaxf(fmaxf(rmx0, rmx1), rmx2);
+                min9[l - 2] = fminf(fminf(rmn0, rmn1), rmn2);
+            }
+        }
+        const bool inside = y > kBorder && y < h - kBorder && x > kBorder && x < w - kBorder;
+#pragma unroll
+        for (int s = 1; s <= kIntervals; s++) {
+            const float cur = cen[s - 1];
+            const bool cand = inside && (double)mif_fabsf(cur) > K_CONTR_THR_1 &&
+                              ((cur > maxP[s - 1] && cur > maxC[s - 1] && cur > max9[s - 1]) ||
+                               (cur < minP[s - 1] && cur < minC[s - 1] && cur < min9[s - 1]));
+            if (cand) s_queue[atomicAdd(&s_ncand, 1)] = (s << 16) | (ly << 8) | lane;
+        }
+    }
+    __syncthreads();
+    // C. one candidate per thread
+    const int ncand = s_ncand;
+    for (int q = threadIdx.x; q < ncand; q += 256) {
+        const int e = s_queue[q];
+        const int s = e >> 16, ly = (e >> 8) & 0xff, lx = e & 0xff;
+        const float* P = s_d[s - 1] + (ly + 1) * kDetPitch + lx + 1;
+        const float* C = s_d[s] + (ly + 1) * kDetPitch + lx + 1;
+        const float* N = s_d[s + 1] + (ly + 1) * kDetPitch + lx + 1;
+        Stencil t;
+        t.c00 = C[0]; t.cxp = C[1]; t.cxm = C[-1]; t.cyp = C[kDetPitch]; t.cym = C[-kDetPitch];
+        t.cpp = C[kDetPitch + 1]; t.cmm = C[-kDetPitch - 1]; t.cpm = C[kDetPitch - 1]; t.cmp = C[-kDetPitch + 1];
+        t.n00 = N[0]; t.nxp = N[1]; t.nxm = N[-1]; t.nyp = N[kDetPitch]; t.nym = N[-kDetPitch];
+        t.p00 = P[0]; t.pxp = P[1]; t.pxm = P[-1]; t.pyp = P[kDetPitch]; t.pym = P[-kDetPitch];
+        const NewtonStep r = newton_step(t);
+        float4 kp;
+        bool found;
+        if (r.singular) {
+            found = false;
+        } else if (step_converged(r)) {
+            const float c1 = s == 1 ? P[0] : s == 2 ? C[0] : N[0];          // sift.cpp:400
+            found = finish_pixel(r, c1, x0 + lx, y0 + ly, s, o, &kp);
+        } else {
+            // has to move: repeat from global memory (the first step comes out identical)
+            found = refine_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o, x0 + lx,
+                                 y0 + ly, &kp);
+        }
+        if (found) atomicOr(&s_mask[s - 1][ly], 1ull << lx);
+    }
+    __syncthreads();
+    // D.
+    if (threadIdx.x < kIntervals * kDetTH) {
+        const int s1 = threadIdx.x / kDetTH, ly = threadIdx.x % kDetTH;
+        const int y = y0 + ly;
+        if (y < h) {
+            const unsigned long long m = s_mask[s1][ly];
+            const size_t r = (size_t)f * kIntervals * h + s1 * h + y;
+            mask[r * words + blockIdx.x] = m;
+            if (m) atomicAdd(&rowcnt[r], __popcll(m));
+        }
     }
 }
 
@@ -420,7 +589,7 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ dog, siz
                 const int p = off + seen + j;
                 if (p < maxf) {
                     float4 out;
-                    detect_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o,
+                    refine_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o,
                                  (w0 + myword) * 64 + bit, y, &out);
                     kp[base + p] = out;
                 }
@@ -827,7 +996,7 @@ int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc
         }
         if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][2], st));
         MIF_HIP(hipMemsetAsync(O.rowcnt, 0, (size_t)nf * O.rows * sizeof(int), st));
-        hipLaunchKernelGGL(k_detect, dim3((O.w + 255) / 256, O.h, kIntervals * nf), dim3(256), 0, st,
+        hipLaunchKernelGGL(k_detect, dim3(O.words, (O.h + kDetTH - 1) / kDetTH, nf), dim3(256), 0, st,
                            (const float*)O.dog, dog_stride, O.mask, O.rowcnt, O.w, O.h, O.words, o);
         hipLaunchKernelGGL(k_scan_rows, dim3(nf), dim3(1024), 0, st, (const int*)O.rowcnt, O.rowoff, O.rows, O.maxf,
                            o, s->counts);
