@@ -71,14 +71,26 @@ __device__ __forceinline__ void top2_insert(Top2& t, float s, int i)
 // grid: (ceil(nq_cap / 128), nsplit, npairs). Wave v of block b owns query rows
 // [128 b + 32 v, +32); the block walks its share of the database in chunks of
 // 32 rows staged in LDS and shared by the four waves.
-template <int KSTEPS>
+//
+// The queries are the B operand of the MFMA and live in registers for the whole
+// kernel: lane l holds q[query l&31][2 kk + (l>>5)] for kk = 0 .. KSTEPS-1. The
+// database chunk is the A operand, staged as s_b[half][row][kk] = d[row][2 kk +
+// half], so a lane fetches four k-steps with one ds_read_b128; rows are 16 B
+// apart modulo the bank row (pitch KSTEPS + 4), which keeps those reads
+// conflict free. The next
+// chunk's global loads are issued before the MFMA loop of the current chunk
+// and only waited for at the following LDS store.
+template <int KSTEPS, bool VEC>
 __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int nq_cap, int nd_cap, int dim, int ld,
                                                        const float* __restrict__ qn, const float* __restrict__ dn,
                                                        int nsplit, float* __restrict__ part_s,
                                                        int* __restrict__ part_i)
 {
-    constexpr int KP = 2 * KSTEPS + 1;     // odd pitch: conflict-free column reads
-    __shared__ float s_b[kDC * KP];
+    constexpr int K = 2 * KSTEPS;
+    constexpr int KP = KSTEPS + 4;
+    constexpr int NV = K / 32;             // float4 (or 4 scalars) staged per thread and chunk
+    __shared__ __attribute__((aligned(16))) float s_b[2 * kDC * KP];
+    __shared__ __attribute__((aligned(16))) float s_dn[kDC];
     const mif_match_pair& pr = tbl.p[blockIdx.z];
     const float* __restrict__ Q = pr.d_q;
     const float* __restrict__ D = pr.d_db;
@@ -98,10 +110,10 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int nq_cap
     const int qbase = blockIdx.x * (kQT * kWaves) + wave * kQT;
     if (blockIdx.x * (kQT * kWaves) >= nq) return;          // uniform over the block
 
-    // A fragments: lane holds q[qbase + col][2 kk + half]
+    // B fragments (queries): lane holds q[qbase + col][2 kk + half]
     float qf[KSTEPS];
+    const int qi = qbase + col;
     {
-        const int qi = qbase + col;
         const float* qr = Q + (size_t)min(qi, nq_cap - 1) * ld;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; kk++) {
@@ -109,70 +121,109 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int nq_cap
             qf[kk] = (qi < nq && k < dim) ? qr[k] : 0.0f;
         }
     }
-    // rows of the 32x32 result held by this lane: (reg&3) + 8 (reg>>2) + 4 half
-    float qnr[16];
-    Top2 best[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int row = qbase + (r & 3) + 8 * (r >> 2) + 4 * half;
-        qnr[r] = (row < nq) ? qn[row] : 0.0f;
-        best[r].s1 = best[r].s2 = kInf;
-        best[r].i1 = best[r].i2 = 0x7fffffff;
-    }
+    // The 32x32 result tile has the database row on the register index and the
+    // query on the lane: C[(reg&3) + 8 (reg>>2) + 4 half][col]. A lane therefore
+    // keeps ONE running top-2 for its query; lanes l and l + 32 hold the same
+    // query and are merged at the end.
+    const float qnv = (qi < nq) ? qn[qi] : 0.0f;
+    Top2 best;
+    best.s1 = best.s2 = kInf;
+    best.i1 = best.i2 = 0x7fffffff;
 
     const int chunks = (nd + kDC - 1) / kDC;
     const int per = (chunks + nsplit - 1) / nsplit;
     const int c_lo = blockIdx.y * per;
     const int c_hi = min(chunks, c_lo + per);
-    for (int c = c_lo; c < c_hi; c++) {
-        __syncthreads();
-        for (int idx = tid; idx < kDC * 2 * KSTEPS; idx += 256) {
-            const int r = idx / (2 * KSTEPS);
-            const int k = idx - r * (2 * KSTEPS);
+
+    float4 stage[NV];
+    float stage_dn = 0.0f;
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int it = 0; it < NV; it++) {
+            const int idx = tid + it * 256;
+            const int r = idx / (K / 4);
+            const int k4 = idx - r * (K / 4);
             const int j = c * kDC + r;
-            s_b[r * KP + k] = (j < nd && k < dim) ? D[(size_t)j * ld + k] : 0.0f;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < nd) {
+                const float* src = D + (size_t)j * ld + 4 * k4;
+                if (VEC) {
+                    if (4 * k4 < dim) v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (4 * k4 + 0 < dim) v.x = src[0];
+                    if (4 * k4 + 1 < dim) v.y = src[1];
+                    if (4 * k4 + 2 < dim) v.z = src[2];
+                    if (4 * k4 + 3 < dim) v.w = src[3];
+                }
+                if (4 * k4 + 1 >= dim) v.y = 0.f;
+                if (4 * k4 + 2 >= dim) v.z = 0.f;
+                if (4 * k4 + 3 >= dim) v.w = 0.f;
+            }
+            stage[it] = v;
         }
+        if (tid < kDC) stage_dn = (c * kDC + tid < nd) ? dn[c * kDC + tid] : 0.0f;
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int it = 0; it < NV; it++) {
+            const int idx = tid + it * 256;
+            const int r = idx / (K / 4);
+            const int k4 = idx - r * (K / 4);
+            // k = 4 k4 + {0, 2} -> half 0, kk = 2 k4 + {0, 1};  k = 4 k4 + {1, 3} -> half 1
+            *reinterpret_cast<float2*>(&s_b[(0 * kDC + r) * KP + 2 * k4]) = make_float2(stage[it].x, stage[it].z);
+            *reinterpret_cast<float2*>(&s_b[(1 * kDC + r) * KP + 2 * k4]) = make_float2(stage[it].y, stage[it].w);
+        }
+        if (tid < kDC) s_dn[tid] = stage_dn;
+    };
+
+    if (c_lo < c_hi) load_chunk(c_lo);
+    for (int c = c_lo; c < c_hi; c++) {
+        __syncthreads();                   // every wave is done reading the previous chunk
+        store_chunk();
         __syncthreads();
+        if (c + 1 < c_hi) load_chunk(c + 1);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+        const float4* ap = reinterpret_cast<const float4*>(&s_b[(half * kDC + col) * KP]);
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; kk++) {
-            const float b = s_b[col * KP + 2 * kk + half];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[kk], b, acc, 0, 0, 0);
+        for (int q4 = 0; q4 < KSTEPS / 4; q4++) {
+            const float4 a = ap[q4];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[4 * q4 + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[4 * q4 + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[4 * q4 + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[4 * q4 + 3], acc, 0, 0, 0);
         }
-        const int j = c * kDC + col;
-        if (j < nd) {
-            const float dnj = dn[j];
+        // ascending database index within the lane: strict '<' keeps the lowest index on ties
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const float s = __builtin_fmaf(-2.0f, acc[r], qnr[r] + dnj);
-                // j grows monotonically per lane, so strict '<' keeps the lowest index on ties
-                if (s < best[r].s1) {
-                    best[r].s2 = best[r].s1; best[r].i2 = best[r].i1;
-                    best[r].s1 = s; best[r].i1 = j;
-                } else if (s < best[r].s2) {
-                    best[r].s2 = s; best[r].i2 = j;
+        for (int g = 0; g < 4; g++) {
+            const float4 dn4 = *reinterpret_cast<const float4*>(&s_dn[8 * g + 4 * half]);
+            const float dnr[4] = {dn4.x, dn4.y, dn4.z, dn4.w};
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const int j = c * kDC + 8 * g + 4 * half + t;
+                const float sc = __builtin_fmaf(-2.0f, acc[4 * g + t], qnv + dnr[t]);
+                if (j < nd) {
+                    if (sc < best.s1) {
+                        best.s2 = best.s1; best.i2 = best.i1;
+                        best.s1 = sc; best.i1 = j;
+                    } else if (sc < best.s2) {
+                        best.s2 = sc; best.i2 = j;
+                    }
                 }
             }
         }
     }
-    // merge the 32 lanes (database columns) of each half
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        Top2 t = best[r];
-#pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            const float os1 = __shfl_xor(t.s1, off), os2 = __shfl_xor(t.s2, off);
-            const int oi1 = __shfl_xor(t.i1, off), oi2 = __shfl_xor(t.i2, off);
-            top2_insert(t, os1, oi1);
-            top2_insert(t, os2, oi2);
-        }
-        const int row = qbase + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (col == 0 && row < nq) {
-            const size_t o = ((size_t)blockIdx.y * nq_cap + row) * 2;
-            part_s[o] = t.s1; part_s[o + 1] = t.s2;
-            part_i[o] = t.i1; part_i[o + 1] = t.i2;
+    // merge the two halves of the wave (same query, interleaved database rows)
+    {
+        const float os1 = __shfl_xor(best.s1, 32), os2 = __shfl_xor(best.s2, 32);
+        const int oi1 = __shfl_xor(best.i1, 32), oi2 = __shfl_xor(best.i2, 32);
+        top2_insert(best, os1, oi1);
+        top2_insert(best, os2, oi2);
+        if (half == 0 && qi < nq) {
+            const size_t o = ((size_t)blockIdx.y * nq_cap + qi) * 2;
+            part_s[o] = best.s1; part_s[o + 1] = best.s2;
+            part_i[o] = best.i1; part_i[o + 1] = best.i2;
         }
     }
 }
@@ -309,12 +360,18 @@ void free_matcher(mif_matcher* m)
     (void)hipFree(m->d_q); (void)hipFree(m->d_db); (void)hipFree(m->d_idx); (void)hipFree(m->d_dist);
 }
 
-int pick_split(int nq, int nd, int npairs)
+int pick_split(int nq, int nd, int npairs, bool device_counts)
 {
-    // enough blocks to cover the chip a few times over, but no split smaller than 8 chunks
+    // Enough blocks to load every CU several times over, but no split shorter than 8 chunks.
+    // With device-side row counts nq / nd are capacities; the rows present are assumed to be
+    // an eighth of them (blocks beyond the real counts exit at once).
+    if (device_counts) {
+        nq = std::max(1, nq / 8);
+        nd = std::max(1, nd / 8);
+    }
     const int qblocks = npairs * ((nq + kQT * kWaves - 1) / (kQT * kWaves));
     const int chunks = (nd + kDC - 1) / kDC;
-    int split = (1024 + qblocks - 1) / qblocks;
+    int split = (4096 + qblocks - 1) / qblocks;
     split = std::min(split, std::max(1, chunks / 8));
     return std::max(1, std::min(split, kMaxSplit));
 }
@@ -354,17 +411,22 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
         float* dn = m->dn + (size_t)base * m->max_d;
         float* ps = m->part_s + (size_t)base * kMaxSplit * m->max_q * 2;
         int* pi = m->part_i + (size_t)base * kMaxSplit * m->max_q * 2;
-        const int nsplit = pick_split(nq, nd, np);
+        bool device_counts = false;
+        for (int i = 0; i < np; i++) device_counts = device_counts || tbl.p[i].d_nq || tbl.p[i].d_nd;
+        const int nsplit = pick_split(nq, nd, np, device_counts);
         if (nd > 0) {
             hipLaunchKernelGGL(k_row_norms, dim3((nd + 255) / 256, np), dim3(256), 0, st, tbl, 1, nd, dim, ld, dn);
             hipLaunchKernelGGL(k_row_norms, dim3((nq + 255) / 256, np), dim3(256), 0, st, tbl, 0, nq, dim, ld, qn);
             dim3 grid((nq + kQT * kWaves - 1) / (kQT * kWaves), nsplit, np);
-            if (dim <= 64)
-                hipLaunchKernelGGL((k_match_partial<32>), grid, dim3(256), 0, st, tbl, nq, nd, dim, ld,
-                                   (const float*)qn, (const float*)dn, nsplit, ps, pi);
-            else
-                hipLaunchKernelGGL((k_match_partial<64>), grid, dim3(256), 0, st, tbl, nq, nd, dim, ld,
-                                   (const float*)qn, (const float*)dn, nsplit, ps, pi);
+            // 16-byte loads of database rows need ld % 4 == 0 and 16-byte aligned row starts
+            bool vec = (ld % 4) == 0;
+            for (int i = 0; i < np; i++) vec = vec && ((reinterpret_cast<uintptr_t>(tbl.p[i].d_db) & 15u) == 0);
+#define MIF_LAUNCH_PARTIAL(KS, V)                                                                             \
+    hipLaunchKernelGGL((k_match_partial<KS, V>), grid, dim3(256), 0, st, tbl, nq, nd, dim, ld, (const float*)qn, \
+                       (const float*)dn, nsplit, ps, pi)
+            if (dim <= 64) { if (vec) MIF_LAUNCH_PARTIAL(32, true); else MIF_LAUNCH_PARTIAL(32, false); }
+            else           { if (vec) MIF_LAUNCH_PARTIAL(64, true); else MIF_LAUNCH_PARTIAL(64, false); }
+#undef MIF_LAUNCH_PARTIAL
         }
         hipLaunchKernelGGL(k_match_finalize, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim, ld,
                            nsplit, (const float*)ps, (const int*)pi);
