@@ -128,6 +128,56 @@ int mif_sift_stage_times(mif_sift* s, float ms[MIF_SIFT_OCTAVES][MIF_SIFT_STAGES
 /* GPU time of the last synchronised frame in ms (hipEvent pair). */
 int mif_sift_last_elapsed_ms(mif_sift* s, float* ms);
 
+/* ------------------------------------------------------------------ SURF -- */
+
+typedef struct mif_surf mif_surf;
+
+/* Interest point with its 64-d descriptor: the layout of ccl_surf::Ipoint
+ * (SURF/coopcl_surf/ccl_surf/ccl_surf.h:11-19). */
+typedef struct mif_ipoint {
+    float x;
+    float y;
+    float scale;
+    float orientation;
+    int32_t laplacian;
+    int32_t clusterIndex;
+    float descriptor[64];
+} mif_ipoint;
+
+#define MIF_SURF_LAYERS 8        /* response layers for OCTAVES = 3 (ccl_surf.cpp:115-153) */
+#define MIF_SURF_MAX_POINTS 8000 /* INIT_FEATS, surf_constants.h */
+
+/* Replaces ccl_surf::initialize_surf_driver + the Surf / FastHessian
+ * constructors (ccl_surf.cpp:822-857, 604-663, 181-214) for a width x height
+ * image with 1 (gray) or 3 (interleaved BGR) 8-bit channels. */
+int mif_surf_create(int device, int width, int height, int channels, mif_surf** out);
+int mif_surf_destroy(mif_surf* s);
+int mif_surf_capacity(const mif_surf* s);
+
+/* Replaces ccl_surf::run (ccl_surf.h:30, ccl_surf.cpp:789-820) for host
+ * buffers: writes *count interest points in the order (non_max_supression
+ * launch, row, column). The reference returns an empty vector when no point is
+ * found; here that is *count = 0 with return value 0. raw_count (may be NULL)
+ * receives the number of accepted positions before the cut at 8000. */
+int mif_surf_run(mif_surf* s, const uint8_t* pixels, mif_ipoint* points, int capacity, int* count, int* raw_count,
+                 float* elapsed_ms);
+
+/* Device-resident form: d_pixels lives in HBM, work is enqueued on the handle's
+ * stream, results stay on the device: pos float2[8000], scale float[8000],
+ * laplacian int32[8000], orientation float[8000], descriptors float[8000][64],
+ * counts int32[2] = {points, raw}. Any out pointer may be NULL. */
+int mif_surf_enqueue(mif_surf* s, const void* d_pixels);
+int mif_surf_sync(mif_surf* s);
+void* mif_surf_stream(mif_surf* s);
+int mif_surf_device_results(mif_surf* s, void** d_pos, void** d_scale, void** d_laplacian, void** d_orientation,
+                            void** d_descriptors, void** d_counts);
+
+/* Probes for tests: the integral image (width*height floats) and one response
+ * layer (responses / laplacians, either may be NULL) of the last frame. */
+int mif_surf_copy_integral(mif_surf* s, float* out);
+int mif_surf_layer_info(const mif_surf* s, int layer, int* width, int* height, int* step, int* filter);
+int mif_surf_copy_layer(mif_surf* s, int layer, float* responses, int32_t* laplacians);
+
 /* -------------------------------------------------------------- matching -- */
 
 typedef struct mif_matcher mif_matcher;

@@ -39,6 +39,17 @@ SYMBOLS = [
     ("mif_sift_set_timing", C.c_int, [_P, C.c_int]),
     ("mif_sift_stage_times", C.c_int, [_P, _P]),
     ("mif_sift_last_elapsed_ms", C.c_int, [_P, _PF]),
+    ("mif_surf_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("mif_surf_destroy", C.c_int, [_P]),
+    ("mif_surf_capacity", C.c_int, [_P]),
+    ("mif_surf_run", C.c_int, [_P, _P, _P, C.c_int, _PI, _PI, _PF]),
+    ("mif_surf_enqueue", C.c_int, [_P, _P]),
+    ("mif_surf_sync", C.c_int, [_P]),
+    ("mif_surf_stream", _P, [_P]),
+    ("mif_surf_device_results", C.c_int, [_P] + [C.POINTER(_P)] * 6),
+    ("mif_surf_copy_integral", C.c_int, [_P, _P]),
+    ("mif_surf_layer_info", C.c_int, [_P, C.c_int, _PI, _PI, _PI, _PI]),
+    ("mif_surf_copy_layer", C.c_int, [_P, C.c_int, _P, _P]),
     ("mif_match_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("mif_match_create_batched", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("mif_match_destroy", C.c_int, [_P]),

@@ -1,0 +1,852 @@
+// GPU-resident SURF for MI355X (gfx950): integral image by wavefront prefix
+// scans, Fast-Hessian response layers, 3-D non-maximum suppression with
+// sub-pixel interpolation, Haar-wavelet orientation and 64-d descriptors.
+//
+// Replaces the reference's host pipeline (SURF/coopcl_surf/ccl_surf/ccl_surf.cpp)
+// and its OpenCL kernels (SURF/coopcl_surf/CLSource/*.cl). Differences in
+// structure, none in results:
+//  * the integral image is a row scan followed by a column scan in place of
+//    scan / transpose / scan / transpose (16 B per pixel instead of 32); both
+//    scans keep the reference's association: Kogge-Stone over blocks of 64
+//    elements plus the running total of the previous blocks;
+//  * the 8 hessian_det launches are one launch, the 6 non_max_supression
+//    launches are one launch that only marks accepted positions in a bitmask;
+//    the interest points are then written in the fixed order (launch, row,
+//    column) instead of atomic arrival order;
+//  * the 109 orientation samples of a point sit in ascending work-item order.
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include "mif_common.h"
+#include "mif_math.h"
+
+namespace {
+
+constexpr int kOctaves = 3;          // OCTAVES, surf_constants.h
+constexpr int kSampleStep = 5;       // SAMPLE_STEP
+constexpr float kThres = 0.0001f;    // THRES
+constexpr int kMaxIpts = 8000;       // INIT_FEATS
+constexpr int kLayers = 8;
+constexpr int kNms = 6;              // non_max_supression launches: 3 octaves x 2
+constexpr float kPiF = 3.14159274101257f;   // M_PI_F of OpenCL C
+
+struct LayerDesc {
+    int w, h, step, filter;
+    size_t off;                      // offset of the layer in the response / laplacian pools
+};
+
+struct LayerTable {
+    LayerDesc l[kLayers];
+};
+
+struct NmsDesc {
+    int b, m, t;                     // layer indices (ccl_surf.cpp:109-113 filter_map)
+    int row0;                        // first row of this launch in the row tables
+};
+
+struct NmsTable {
+    NmsDesc n[kNms];
+    int words;                       // bitmask words per row
+    int rows;                        // total rows
+};
+
+// ccl_surf.cpp:743-762
+__constant__ int c_tab_j[16] = {-12, -7, -2, 3, -12, -7, -2, 3, -12, -7, -2, 3, -12, -7, -2, 3};
+__constant__ int c_tab_i[16] = {-12, -12, -12, -12, -7, -7, -7, -7, -2, -2, -2, -2, 3, 3, 3, 3};
+__constant__ unsigned c_tab_id[13] = {6, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5, 6};
+__constant__ float c_gauss25[49] = {
+    0.02350693969273f, 0.01849121369071f, 0.01239503121241f, 0.00708015417522f, 0.00344628101733f, 0.00142945847484f, 0.00050524879060f,
+    0.02169964028389f, 0.01706954162243f, 0.01144205592615f, 0.00653580605408f, 0.00318131834134f, 0.00131955648461f, 0.00046640341759f,
+    0.01706954162243f, 0.01342737701584f, 0.00900063997939f, 0.00514124713667f, 0.00250251364222f, 0.00103799989504f, 0.00036688592278f,
+    0.01144205592615f, 0.00900063997939f, 0.00603330940534f, 0.00344628101733f, 0.00167748505986f, 0.00069579213743f, 0.00024593098864f,
+    0.00653580605408f, 0.00514124713667f, 0.00344628101733f, 0.00196854695367f, 0.00095819467066f, 0.00039744277546f, 0.00014047800980f,
+    0.00318131834134f, 0.00250251364222f, 0.00167748505986f, 0.00095819467066f, 0.00046640341759f, 0.00019345616757f, 0.00006837798818f,
+    0.00131955648461f, 0.00103799989504f, 0.00069579213743f, 0.00039744277546f, 0.00019345616757f, 0.00008024231247f, 0.00002836202103f};
+// work items of getOrientationStep1 (13 x 13 grid) with i*i + j*j < 36, ascending
+__constant__ unsigned char c_orient_item[109];
+
+// ---------------------------------------------------------- integral image
+
+// Gray value of one 8-bit pixel as the reference's host code produces it
+// through OpenCV (ccl_surf.cpp:422-449): cvtColor BGR2GRAY fixed point
+// (b*1868 + g*9617 + r*4899 + 8192) >> 14, then convertTo(CV_32F, 1/255).
+__device__ __forceinline__ float gray_of(const uint8_t* __restrict__ px, int i, int channels)
+{
+    int g;
+    if (channels == 3) {
+        const int b = px[3 * i], gg = px[3 * i + 1], r = px[3 * i + 2];
+        g = (b * 1868 + gg * 9617 + r * 4899 + (1 << 13)) >> 14;
+    } else {
+        g = px[i];
+    }
+    return (float)((double)g * (1.0 / 255.0));
+}
+
+// Inclusive scan over the 64 lanes of a wave with offsets 1, 2, ..., 32: the
+// association tree of the reference's local-memory scan
+// (integralImage_kernels.cl:120-141).
+__device__ __forceinline__ float wave_scan64(float v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float u = __shfl_up(v, d);
+        v = v + (lane >= d ? u : 0.0f);
+    }
+    return v;
+}
+
+// Row pass (integralImage_kernels.cl:63-152 `scan`, fused with the gray
+// conversion): one wave per image row marches along it 64 pixels at a time.
+__global__ __launch_bounds__(256) void k_scan_rows(const uint8_t* __restrict__ px, float* __restrict__ out, int w,
+                                                   int h, int channels)
+{
+    const int lane = threadIdx.x & 63;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= h) return;
+    float prev = 0.0f;
+    for (int x0 = 0; x0 < w; x0 += 64) {
+        const int x = x0 + lane;
+        float v = (x < w) ? gray_of(px, y * w + x, channels) : 0.0f;
+        v = wave_scan64(v, lane);
+        if (x < w) out[(size_t)y * w + x] = v + prev;
+        prev += __shfl(v, 63);
+    }
+}
+
+// Column pass: the same scan along y (the reference transposes, scans rows and
+// transposes back, ccl_surf.cpp:504-539). A lane owns one column; it loads 64
+// rows, runs the Kogge-Stone tree over them in registers (descending index, so
+// every step reads values of the previous step), adds the running total and
+// stores. Lanes of a wave read consecutive x, so every access is coalesced.
+__global__ __launch_bounds__(64) void k_scan_cols(float* __restrict__ img, int w, int h)
+{
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    if (x >= w) return;
+    float prev = 0.0f;
+    for (int y0 = 0; y0 < h; y0 += 64) {
+        float a[64];
+#pragma unroll
+        for (int i = 0; i < 64; i++) a[i] = (y0 + i < h) ? img[(size_t)(y0 + i) * w + x] : 0.0f;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+            for (int i = 63; i >= d; i--) a[i] = a[i] + a[i - d];
+        }
+#pragma unroll
+        for (int i = 0; i < 64; i++)
+            if (y0 + i < h) img[(size_t)(y0 + i) * w + x] = a[i] + prev;
+        prev += a[63];
+    }
+}
+
+// ------------------------------------------------------------- box filters
+
+// hessianDet_kernel.cl:77-103 BoxIntegral (same text in the orientation and
+// descriptor kernel files)
+__device__ __forceinline__ float box_integral(const float* __restrict__ data, int width, int height, int row, int col,
+                                              int rows, int cols)
+{
+    float A = 0.0f, B = 0.0f, C = 0.0f, D = 0.0f;
+    const int r1 = min(row, height) - 1;
+    const int c1 = min(col, width) - 1;
+    const int r2 = min(row + rows, height) - 1;
+    const int c2 = min(col + cols, width) - 1;
+    if (r1 >= 0 && c1 >= 0) A = data[r1 * width + c1];
+    if (r1 >= 0 && c2 >= 0) B = data[r1 * width + c2];
+    if (r2 >= 0 && c1 >= 0) C = data[r2 * width + c1];
+    if (r2 >= 0 && c2 >= 0) D = data[r2 * width + c2];
+    return fmaxf(0.0f, A - B - C + D);
+}
+
+__device__ __forceinline__ float haar_x(const float* __restrict__ img, int w, int h, int row, int column, int s)
+{
+    return box_integral(img, w, h, row - s / 2, column, s, s / 2) -
+           box_integral(img, w, h, row - s / 2, column - s / 2, s, s / 2);
+}
+
+__device__ __forceinline__ float haar_y(const float* __restrict__ img, int w, int h, int row, int column, int s)
+{
+    return box_integral(img, w, h, row, column - s / 2, s / 2, s) -
+           box_integral(img, w, h, row - s / 2, column - s / 2, s / 2, s);
+}
+
+// hessianDet_kernel.cl:105-175 for all eight layers in one launch
+// (grid.z = layer). Work items beyond the layer do not write (the reference's
+// guard only checks the image bounds and writes one element past the row).
+__global__ __launch_bounds__(256) void k_hessian(const float* __restrict__ img, int width, int height, LayerTable tab,
+                                                 float* __restrict__ responses, int* __restrict__ laplacians)
+{
+    const LayerDesc L = tab.l[blockIdx.z];
+    const int idx = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int idy = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (idx >= L.w || idy >= L.h) return;
+    const int w = L.filter;
+    const int l = L.filter / 3;
+    const int b = (L.filter - 1) / 2 + 1;
+    const float inverse_area = 1.0f / (w * w);
+    const int r = idy * L.step;
+    const int c = idx * L.step;
+    if (r >= height || c >= width) return;
+    float Dxx = box_integral(img, width, height, r - l + 1, c - b, 2 * l - 1, w) -
+                box_integral(img, width, height, r - l + 1, c - l / 2, 2 * l - 1, l) * 3;
+    float Dyy = box_integral(img, width, height, r - b, c - l + 1, w, 2 * l - 1) -
+                box_integral(img, width, height, r - l / 2, c - l + 1, l, 2 * l - 1) * 3;
+    float Dxy = box_integral(img, width, height, r - l, c + 1, l, l) +
+                box_integral(img, width, height, r + 1, c - l, l, l) -
+                box_integral(img, width, height, r - l, c - l, l, l) -
+                box_integral(img, width, height, r + 1, c + 1, l, l);
+    Dxx *= inverse_area;
+    Dyy *= inverse_area;
+    Dxy *= inverse_area;
+    responses[L.off + idy * L.w + idx] = (Dxx * Dyy - 0.81f * Dxy * Dxy);
+    laplacians[L.off + idy * L.w + idx] = (Dxx + Dyy >= 0 ? 1 : 0);
+}
+
+// ------------------------------------------------------------------- NMS
+
+struct LayerView {
+    const float* resp;
+    const int* lap;
+    int w, h, step, filter;
+};
+
+__device__ __forceinline__ LayerView view_of(const LayerTable& tab, int i, const float* responses, const int* laps)
+{
+    LayerView v;
+    v.resp = responses + tab.l[i].off;
+    v.lap = laps + tab.l[i].off;
+    v.w = tab.l[i].w; v.h = tab.l[i].h; v.step = tab.l[i].step; v.filter = tab.l[i].filter;
+    return v;
+}
+
+__device__ __forceinline__ float resp_at(const LayerView& L, int c, int r, int scale)
+{
+    return L.resp[r * scale * L.w + c * scale];
+}
+
+// nonMaxSuppression_kernel.cl:232-296 isExtremum
+__device__ bool is_extremum(const LayerView& t, const LayerView& m, const LayerView& b, int c, int r, float threshold)
+{
+    const int layerBorder = (t.filter + 1) / (2 * t.step);
+    if (r <= layerBorder || r >= t.h - layerBorder || c <= layerBorder || c >= t.w - layerBorder) return false;
+    const int mScale = m.w / t.w;
+    const float candidate = resp_at(m, c, r, mScale);
+    if (candidate < threshold) return false;
+    const int bScale = b.w / t.w;
+    float localMax = resp_at(t, c - 1, r - 1, 1);
+#pragma unroll
+    for (int dr = -1; dr <= 1; dr++)
+#pragma unroll
+        for (int dc = -1; dc <= 1; dc++) {
+            localMax = fmaxf(localMax, resp_at(t, c + dc, r + dr, 1));
+            localMax = fmaxf(localMax, resp_at(b, c + dc, r + dr, bScale));
+            if (dr != 0 || dc != 0) localMax = fmaxf(localMax, resp_at(m, c + dc, r + dr, mScale));
+        }
+    return !(localMax > candidate);
+}
+
+struct IptCore {
+    float x, y, scale;
+    int laplacian;
+};
+
+// nonMaxSuppression_kernel.cl:107-228 interpolateExtremum
+__device__ bool interpolate_extremum(const LayerView& t, const LayerView& m, const LayerView& b, int r, int c,
+                                     IptCore* out)
+{
+    const int mScale = m.w / t.w;
+    const int bScale = b.w / t.w;
+    const float dx = (resp_at(m, c + 1, r, mScale) - resp_at(m, c - 1, r, mScale)) / 2.0f;
+    const float dy = (resp_at(m, c, r + 1, mScale) - resp_at(m, c, r - 1, mScale)) / 2.0f;
+    const float ds = (resp_at(t, c, r, 1) - resp_at(b, c, r, bScale)) / 2.0f;
+    const float v = resp_at(m, c, r, mScale);
+    const float dxx = resp_at(m, c + 1, r, mScale) + resp_at(m, c - 1, r, mScale) - 2.0f * v;
+    const float dyy = resp_at(m, c, r + 1, mScale) + resp_at(m, c, r - 1, mScale) - 2.0f * v;
+    const float dss = resp_at(t, c, r, 1) + resp_at(b, c, r, bScale) - 2.0f * v;
+    const float dxy = (resp_at(m, c + 1, r + 1, mScale) - resp_at(m, c - 1, r + 1, mScale) -
+                       resp_at(m, c + 1, r - 1, mScale) + resp_at(m, c - 1, r - 1, mScale)) / 4.0f;
+    const float dxs = (resp_at(t, c + 1, r, 1) - resp_at(t, c - 1, r, 1) - resp_at(b, c + 1, r, bScale) +
+                       resp_at(b, c - 1, r, bScale)) / 4.0f;
+    const float dys = (resp_at(t, c, r + 1, 1) - resp_at(t, c, r - 1, 1) - resp_at(b, c, r + 1, bScale) +
+                       resp_at(b, c, r - 1, bScale)) / 4.0f;
+    const float H0 = dxx, H1 = dxy, H2 = dxs, H3 = dxy, H4 = dyy, H5 = dys, H6 = dxs, H7 = dys, H8 = dss;
+    const float determinant = H0 * (H4 * H8 - H7 * H5) - H1 * (H3 * H8 - H5 * H6) + H2 * (H3 * H7 - H4 * H6);
+    const float invdet = 1.0f / determinant;
+    const float invH0 = (H4 * H8 - H7 * H5) * invdet;
+    const float invH1 = -(H3 * H8 - H5 * H6) * invdet;
+    const float invH2 = (H3 * H7 - H6 * H4) * invdet;
+    const float invH3 = -(H1 * H8 - H2 * H7) * invdet;
+    const float invH4 = (H0 * H8 - H2 * H6) * invdet;
+    const float invH5 = -(H0 * H7 - H6 * H1) * invdet;
+    const float invH6 = (H1 * H5 - H2 * H4) * invdet;
+    const float invH7 = -(H0 * H5 - H3 * H2) * invdet;
+    const float invH8 = (H0 * H4 - H3 * H1) * invdet;
+    float xi, xr, xc;
+    xc = invH0 * dx * -1.0f;
+    xc += invH1 * dy * -1.0f;
+    xc += invH2 * ds * -1.0f;
+    xr = invH3 * dx * -1.0f;
+    xr += invH4 * dy * -1.0f;
+    xr += invH5 * ds * -1.0f;
+    xi = invH6 * dx * -1.0f;
+    xi += invH7 * dy * -1.0f;
+    xi += invH8 * ds * -1.0f;
+    if (mif_fabsf(xi) < 0.5f && mif_fabsf(xr) < 0.5f && mif_fabsf(xc) < 0.5f) {
+        const int filterStep = m.filter - b.filter;
+        out->x = ((float)c + xc) * (float)t.step;
+        out->y = ((float)r + xr) * (float)t.step;
+        out->scale = 0.1333f * ((float)m.filter + (xi * (float)filterStep));
+        out->laplacian = m.lap[(r * mScale) * m.w + c * mScale];
+        return true;
+    }
+    return false;
+}
+
+// nonMaxSuppression_kernel.cl:306-364 for the six (bottom, middle, top)
+// triples in one launch: grid (words, max middle height, 6). The work items of
+// a launch span the middle layer; (c, r) are read as top-layer coordinates. A
+// wave stores its ballot of accepted positions as one bitmask word and adds
+// its count to the row total.
+__global__ __launch_bounds__(64) void k_nms_mark(LayerTable tab, NmsTable nms, const float* __restrict__ responses,
+                                                 const int* __restrict__ laps, float threshold,
+                                                 unsigned long long* __restrict__ mask, int* __restrict__ rowcnt)
+{
+    const NmsDesc d = nms.n[blockIdx.z];
+    const LayerView b = view_of(tab, d.b, responses, laps);
+    const LayerView m = view_of(tab, d.m, responses, laps);
+    const LayerView t = view_of(tab, d.t, responses, laps);
+    const int r = blockIdx.y;
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (r >= m.h || blockIdx.x * 64 >= m.w) return;      // uniform over the wave
+    bool found = false;
+    if (c < m.w && t.w > 0 && t.h > 0 && is_extremum(t, m, b, c, r, threshold)) {
+        IptCore p;
+        found = interpolate_extremum(t, m, b, r, c, &p);
+    }
+    const unsigned long long bits = __ballot(found);
+    if (threadIdx.x == 0) {
+        mask[(size_t)(d.row0 + r) * nms.words + blockIdx.x] = bits;
+        if (bits) atomicAdd(&rowcnt[d.row0 + r], __popcll(bits));
+    }
+}
+
+// Exclusive scan of the row totals, point count cut at maxIpts. One block.
+__global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ rowcnt, int* __restrict__ rowoff,
+                                                      int rows, int max_ipts, int* __restrict__ counts)
+{
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (rows + 1023) / 1024;
+    const int lo = min(rows, tid * per), hi = min(rows, lo + per);
+    int sum = 0;
+    for (int i = lo; i < hi; i++) sum += rowcnt[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = (tid >= d) ? s_part[tid - d] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = s_part[tid] - sum;
+    for (int i = lo; i < hi; i++) {
+        rowoff[i] = run;
+        run += rowcnt[i];
+    }
+    if (tid == 1023) {
+        counts[0] = min(s_part[1023], max_ipts);
+        counts[1] = s_part[1023];
+    }
+}
+
+// Writes the accepted positions in (launch, row, column) order: one wave per
+// row; a set bit's rank in the row gives its slot.
+__global__ __launch_bounds__(256) void k_nms_emit(LayerTable tab, NmsTable nms, const float* __restrict__ responses,
+                                                  const int* __restrict__ laps,
+                                                  const unsigned long long* __restrict__ mask,
+                                                  const int* __restrict__ rowcnt, const int* __restrict__ rowoff,
+                                                  int max_ipts, float2* __restrict__ pos, float* __restrict__ scale,
+                                                  int* __restrict__ lap_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nms.rows) return;
+    if (rowcnt[row] == 0) return;
+    int li = 0;
+    for (int i = 1; i < kNms; i++)
+        if (row >= nms.n[i].row0) li = i;
+    const NmsDesc d = nms.n[li];
+    const LayerView b = view_of(tab, d.b, responses, laps);
+    const LayerView m = view_of(tab, d.m, responses, laps);
+    const LayerView t = view_of(tab, d.t, responses, laps);
+    const int r = row - d.row0;
+    int slot = rowoff[row];
+    for (int wd = 0; wd < nms.words; wd++) {
+        const unsigned long long bits = mask[(size_t)row * nms.words + wd];
+        if (bits == 0) continue;
+        if ((bits >> lane) & 1ull) {
+            const int p = slot + __popcll(bits & ((1ull << lane) - 1ull));
+            if (p < max_ipts) {
+                IptCore ip;
+                interpolate_extremum(t, m, b, r, wd * 64 + lane, &ip);
+                pos[p] = make_float2(ip.x, ip.y);
+                scale[p] = ip.scale;
+                lap_out[p] = ip.laplacian;
+            }
+        }
+        slot += __popcll(bits);
+    }
+}
+
+// ------------------------------------------------------------ orientation
+
+// atan of a non-negative (possibly infinite or NaN) argument
+__device__ __forceinline__ float atan_pos(float v)
+{
+    if (v != v) return v;
+    if (v > 1.0f) return MIF_PIO2_F - mif_atan01(1.0f / v);
+    return mif_atan01(v);
+}
+
+// getOrientation_kernels.cl:138-153 getAngle
+__device__ __forceinline__ float get_angle(float X, float Y)
+{
+    if (X >= 0 && Y >= 0) return atan_pos(Y / X);
+    if (X < 0 && Y >= 0) return kPiF - atan_pos(-Y / X);
+    if (X < 0 && Y < 0) return kPiF + atan_pos(Y / X);
+    if (X >= 0 && Y < 0) return 2 * kPiF - atan_pos(-Y / X);
+    return 0;
+}
+
+// getOrientation_kernels.cl:68-71 / createDescriptors_kernel.cl:154-157
+__device__ __forceinline__ float gaussian(float x, float y, float sig)
+{
+    return (1.0f / (2.0f * kPiF * sig * sig)) * mif_expf(-(x * x + y * y) / (2.0f * sig * sig));
+}
+
+// getOrientationStep1 + getOrientationStep2 (getOrientation_kernels.cl:161-316)
+// in one block of 128 threads per interest point: threads 0..108 evaluate the
+// 109 Haar samples, threads 0..41 sum the samples of their pi/3 window in
+// sample order, then the reference's max-magnitude tree picks the winner.
+__global__ __launch_bounds__(128) void k_orientation(const float* __restrict__ img, int w, int h,
+                                                     const float2* __restrict__ pos, const float* __restrict__ scale,
+                                                     const int* __restrict__ counts, float* __restrict__ orientation)
+{
+    __shared__ float s_rx[109], s_ry[109], s_rz[109];
+    __shared__ float s_sx[42], s_sy[42];
+    const int ip = blockIdx.x;
+    if (ip >= counts[0]) return;
+    const int tid = threadIdx.x;
+    const int s = (int)mif_roundf(scale[ip]);
+    const int r = (int)mif_roundf(pos[ip].y);
+    const int c = (int)mif_roundf(pos[ip].x);
+    if (tid < 109) {
+        const int localId = c_orient_item[tid];
+        const int i = localId / 13 - 6;
+        const int j = localId % 13 - 6;
+        const float gauss = c_gauss25[7 * c_tab_id[i + 6] + c_tab_id[j + 6]];
+        const float rx = gauss * haar_x(img, w, h, r + j * s, c + i * s, 4 * s);
+        const float ry = gauss * haar_y(img, w, h, r + j * s, c + i * s, 4 * s);
+        s_rx[tid] = rx;
+        s_ry[tid] = ry;
+        s_rz[tid] = get_angle(rx, ry);
+    }
+    __syncthreads();
+    if (tid < 42) {
+        const float ang1 = 0.15f * (float)tid;
+        const float ang2 = (ang1 + (kPiF / 3.0f) > 2 * kPiF ? ang1 - (5.0f * kPiF / 3.0f) : ang1 + (kPiF / 3.0f));
+        float sx = 0.f, sy = 0.f;
+        if (tid <= 34) {
+            for (int k = 0; k < 109; ++k) {
+                const float ang = s_rz[k];
+                const int check = ang1 < ang && ang < ang2;
+                sx += s_rx[k] * (float)check;
+                sy += s_ry[k] * (float)check;
+            }
+        } else {
+            for (int k = 0; k < 109; ++k) {
+                const float ang = s_rz[k];
+                const int check = ((ang > 0 && ang < ang2) || (ang > ang1 && ang < 2 * kPiF));
+                sx += s_rx[k] * (float)check;
+                sy += s_ry[k] * (float)check;
+            }
+        }
+        s_sx[tid] = sx;
+        s_sy[tid] = sy;
+    }
+    __syncthreads();
+    for (int offset = 32; offset > 0; offset >>= 1) {
+        if (tid < offset && tid + offset < 42) {
+            const float m0 = s_sx[tid] * s_sx[tid] + s_sy[tid] * s_sy[tid];
+            const float m1 = s_sx[tid + offset] * s_sx[tid + offset] + s_sy[tid + offset] * s_sy[tid + offset];
+            if (m0 < m1) {
+                s_sx[tid] = s_sx[tid + offset];
+                s_sy[tid] = s_sy[tid + offset];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) orientation[ip] = get_angle(s_sx[0], s_sy[0]);
+}
+
+// -------------------------------------------------------------- descriptor
+
+// createDescriptors (createDescriptors_kernel.cl:160-275) fused with
+// normalizeDescriptors (normalizeDescriptors_kernel.cl:54-111): one block of
+// 256 threads per interest point evaluates the 16 x 81 rotated Haar samples,
+// 64 threads then run the reference's reduction tree (81 -> 64 -> 32 ... -> 1)
+// per sub-region and component, and the 16 partial squared lengths are summed
+// with its 8-4-2-1 tree.
+__global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ img, int width, int height,
+                                                    const float2* __restrict__ pos, const float* __restrict__ scale,
+                                                    const float* __restrict__ orientation,
+                                                    const int* __restrict__ counts, float* __restrict__ desc)
+{
+    __shared__ float s_d[16][4][81];
+    __shared__ float s_len[16];
+    const int ip = blockIdx.x;
+    if (ip >= counts[0]) return;
+    const int tid = threadIdx.x;
+    const float x = mif_roundf(pos[ip].x);
+    const float y = mif_roundf(pos[ip].y);
+    float si, co;
+    mif_sincosf(orientation[ip], &si, &co);
+    const float thScale = scale[ip];
+    const int hs = (int)(2 * mif_roundf(thScale));
+    for (int item = tid; item < 16 * 81; item += 256) {
+        const int bIdx = item / 81;
+        const int tha = item - bIdx * 81;
+        const int j = c_tab_j[bIdx];
+        const int i = c_tab_i[bIdx];
+        const float ix = (float)(i + 5);
+        const float jx = (float)(j + 5);
+        const float xs = mif_roundf(x + (-jx * thScale * si + ix * thScale * co));
+        const float ys = mif_roundf(y + (jx * thScale * co + ix * thScale * si));
+        const int k = i + (tha / 9);
+        const int l = j + (tha % 9);
+        const int sample_x = (int)mif_roundf(x + ((float)(-l) * thScale * si + (float)k * thScale * co));
+        const int sample_y = (int)mif_roundf(y + ((float)l * thScale * co + (float)k * thScale * si));
+        const float gauss_s1 = gaussian(xs - (float)sample_x, ys - (float)sample_y, 2.5f * thScale);
+        const float rx = haar_x(img, width, height, sample_y, sample_x, hs);
+        const float ry = haar_y(img, width, height, sample_y, sample_x, hs);
+        const float rrx = gauss_s1 * (-rx * si + ry * co);
+        const float rry = gauss_s1 * (rx * co + ry * si);
+        s_d[bIdx][0][tha] = rrx;
+        s_d[bIdx][1][tha] = rry;
+        s_d[bIdx][2][tha] = mif_fabsf(rrx);
+        s_d[bIdx][3][tha] = mif_fabsf(rry);
+    }
+    __syncthreads();
+    float mine = 0.0f;
+    if (tid < 64) {
+        const int bIdx = tid >> 2, q = tid & 3;
+        float* v = s_d[bIdx][q];
+        for (int t = 0; t < 81 - 64; t++) v[t] += v[t + 64];          // sumDesc, first step
+        for (int stride = 32; stride > 0; stride >>= 1)
+            for (int t = 0; t < stride; t++) v[t] += v[t + stride];
+        float cx = 0.5f, cy = 0.5f;
+        cx += (float)(bIdx / 4);
+        cy += (float)(bIdx % 4);
+        mine = v[0] * gaussian(cx - 2.0f, cy - 2.0f, 1.5f);
+        v[0] = mine;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const float a = s_d[tid][0][0], b = s_d[tid][1][0], c = s_d[tid][2][0], d = s_d[tid][3][0];
+        s_len[tid] = a * a + b * b + c * c + d * d;
+    }
+    __syncthreads();
+    for (int i = 8; i > 0; i >>= 1) {
+        if (tid < i) s_len[tid] += s_len[tid + i];
+        __syncthreads();
+    }
+    if (tid < 64) {
+        const float lengthOfDescriptor = 1.0f / __builtin_sqrtf(s_len[0]);
+        desc[(size_t)ip * 64 + tid] = mine * lengthOfDescriptor;
+    }
+}
+
+} // namespace
+
+struct mif_surf {
+    int device = 0, W = 0, H = 0, C = 1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    LayerTable tab;
+    NmsTable nms;
+    size_t pool = 0;
+    int nms_max_h = 0;
+    uint8_t* d_pixels = nullptr;
+    float* integral = nullptr;
+    float* responses = nullptr;
+    int* laplacians = nullptr;
+    unsigned long long* mask = nullptr;
+    int* rowcnt = nullptr;
+    int* rowoff = nullptr;
+    int* counts = nullptr;               // {points (cut at 8000), raw total}
+    float2* pos = nullptr;
+    float* scale = nullptr;
+    int* lap = nullptr;
+    float* orient = nullptr;
+    float* desc = nullptr;
+    int* h_counts = nullptr;
+    std::vector<float> h_f;              // staging for mif_surf_run
+    std::vector<int> h_i;
+};
+
+namespace {
+
+void surf_free(mif_surf* s)
+{
+    (void)hipFree(s->d_pixels); (void)hipFree(s->integral); (void)hipFree(s->responses);
+    (void)hipFree(s->laplacians); (void)hipFree(s->mask); (void)hipFree(s->rowcnt); (void)hipFree(s->rowoff);
+    (void)hipFree(s->counts); (void)hipFree(s->pos); (void)hipFree(s->scale); (void)hipFree(s->lap);
+    (void)hipFree(s->orient); (void)hipFree(s->desc);
+    if (s->h_counts) (void)hipHostFree(s->h_counts);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+}
+
+int surf_create_impl(mif_surf* s)
+{
+    MIF_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    MIF_HIP(hipEventCreate(&s->ev0));
+    MIF_HIP(hipEventCreate(&s->ev1));
+    // ccl_surf.cpp:115-153 createResponseMap for OCTAVES = 3, SAMPLE_STEP = 5
+    const int w = s->W / kSampleStep, h = s->H / kSampleStep, st = kSampleStep;
+    const int spec[kLayers][4] = {{w, h, st, 9}, {w, h, st, 15}, {w, h, st, 21}, {w, h, st, 27},
+                                  {w / 2, h / 2, st * 2, 39}, {w / 2, h / 2, st * 2, 51},
+                                  {w / 4, h / 4, st * 4, 75}, {w / 4, h / 4, st * 4, 99}};
+    size_t off = 0;
+    for (int i = 0; i < kLayers; i++) {
+        s->tab.l[i].w = spec[i][0]; s->tab.l[i].h = spec[i][1];
+        s->tab.l[i].step = spec[i][2]; s->tab.l[i].filter = spec[i][3];
+        s->tab.l[i].off = off;
+        off += (size_t)spec[i][0] * spec[i][1];
+    }
+    s->pool = off > 0 ? off : 1;
+    // ccl_surf.cpp:109-113 filter_map, 302-337 launch order
+    const int filter_map[kOctaves][4] = {{0, 1, 2, 3}, {1, 3, 4, 5}, {3, 5, 6, 7}};
+    int rows = 0, max_w = 1, max_h = 1, n = 0;
+    for (int o = 0; o < kOctaves; o++)
+        for (int i = 0; i <= 1; i++) {
+            NmsDesc& d = s->nms.n[n++];
+            d.b = filter_map[o][i]; d.m = filter_map[o][i + 1]; d.t = filter_map[o][i + 2];
+            d.row0 = rows;
+            rows += s->tab.l[d.m].h;
+            max_w = std::max(max_w, s->tab.l[d.m].w);
+            max_h = std::max(max_h, s->tab.l[d.m].h);
+        }
+    s->nms.rows = rows;
+    s->nms.words = (max_w + 63) / 64;
+    s->nms_max_h = max_h;
+    const size_t px = (size_t)s->W * s->H;
+    MIF_HIP(hipMalloc(&s->d_pixels, px * s->C));
+    MIF_HIP(hipMalloc(&s->integral, px * sizeof(float)));
+    MIF_HIP(hipMalloc(&s->responses, s->pool * sizeof(float)));
+    MIF_HIP(hipMalloc(&s->laplacians, s->pool * sizeof(int)));
+    MIF_HIP(hipMalloc(&s->mask, (size_t)std::max(rows, 1) * s->nms.words * sizeof(unsigned long long)));
+    MIF_HIP(hipMalloc(&s->rowcnt, (size_t)std::max(rows, 1) * sizeof(int)));
+    MIF_HIP(hipMalloc(&s->rowoff, (size_t)std::max(rows, 1) * sizeof(int)));
+    MIF_HIP(hipMalloc(&s->counts, 2 * sizeof(int)));
+    MIF_HIP(hipMemset(s->counts, 0, 2 * sizeof(int)));
+    MIF_HIP(hipMalloc(&s->pos, kMaxIpts * sizeof(float2)));
+    MIF_HIP(hipMalloc(&s->scale, kMaxIpts * sizeof(float)));
+    MIF_HIP(hipMalloc(&s->lap, kMaxIpts * sizeof(int)));
+    MIF_HIP(hipMalloc(&s->orient, kMaxIpts * sizeof(float)));
+    MIF_HIP(hipMalloc(&s->desc, (size_t)kMaxIpts * 64 * sizeof(float)));
+    MIF_HIP(hipHostMalloc(&s->h_counts, 2 * sizeof(int)));
+    unsigned char items[109];
+    int k = 0;
+    for (int id = 0; id < 169; id++) {
+        const int i = id / 13 - 6, j = id % 13 - 6;
+        if (i * i + j * j < 36) items[k++] = (unsigned char)id;
+    }
+    MIF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_orient_item), items, sizeof(items)));
+    return MIF_OK;
+}
+
+int surf_enqueue(mif_surf* s, const void* d_pixels)
+{
+    hipStream_t st = s->stream;
+    const int w = s->W, h = s->H;
+    MIF_HIP(hipEventRecord(s->ev0, st));
+    hipLaunchKernelGGL(k_scan_rows, dim3((h + 3) / 4), dim3(256), 0, st, (const uint8_t*)d_pixels, s->integral, w, h,
+                       s->C);
+    hipLaunchKernelGGL(k_scan_cols, dim3((w + 63) / 64), dim3(64), 0, st, s->integral, w, h);
+    // layers that are empty keep zero-sized slots; the pools are cleared so that
+    // positions no work item writes read as zero, as in freshly allocated buffers
+    MIF_HIP(hipMemsetAsync(s->responses, 0, s->pool * sizeof(float), st));
+    MIF_HIP(hipMemsetAsync(s->laplacians, 0, s->pool * sizeof(int), st));
+    const int lw = std::max(s->tab.l[0].w, 1), lh = std::max(s->tab.l[0].h, 1);
+    hipLaunchKernelGGL(k_hessian, dim3((lw + 15) / 16, (lh + 15) / 16, kLayers), dim3(256), 0, st,
+                       (const float*)s->integral, w, h, s->tab, s->responses, s->laplacians);
+    MIF_HIP(hipMemsetAsync(s->rowcnt, 0, (size_t)std::max(s->nms.rows, 1) * sizeof(int), st));
+    MIF_HIP(hipMemsetAsync(s->mask, 0, (size_t)std::max(s->nms.rows, 1) * s->nms.words * sizeof(unsigned long long),
+                           st));
+    hipLaunchKernelGGL(k_nms_mark, dim3(s->nms.words, s->nms_max_h, kNms), dim3(64), 0, st, s->tab, s->nms,
+                       (const float*)s->responses, (const int*)s->laplacians, kThres, s->mask, s->rowcnt);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, (const int*)s->rowcnt, s->rowoff, s->nms.rows,
+                       kMaxIpts, s->counts);
+    if (s->nms.rows > 0)
+        hipLaunchKernelGGL(k_nms_emit, dim3((s->nms.rows + 3) / 4), dim3(256), 0, st, s->tab, s->nms,
+                           (const float*)s->responses, (const int*)s->laplacians,
+                           (const unsigned long long*)s->mask, (const int*)s->rowcnt, (const int*)s->rowoff, kMaxIpts,
+                           s->pos, s->scale, s->lap);
+    hipLaunchKernelGGL(k_orientation, dim3(kMaxIpts), dim3(128), 0, st, (const float*)s->integral, w, h,
+                       (const float2*)s->pos, (const float*)s->scale, (const int*)s->counts, s->orient);
+    hipLaunchKernelGGL(k_descriptor, dim3(kMaxIpts), dim3(256), 0, st, (const float*)s->integral, w, h,
+                       (const float2*)s->pos, (const float*)s->scale, (const float*)s->orient, (const int*)s->counts,
+                       s->desc);
+    MIF_HIP(hipGetLastError());
+    MIF_HIP(hipEventRecord(s->ev1, st));
+    return MIF_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int mif_surf_create(int device, int width, int height, int channels, mif_surf** out)
+{
+    if (!out) { mif::set_error("mif_surf_create: out is NULL"); return MIF_ERR_INVALID_ARGUMENT; }
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || (channels != 1 && channels != 3) ||
+        (long long)width * height * 3 >= (1ll << 31)) {
+        mif::set_error("mif_surf_create: bad geometry %dx%dx%d", width, height, channels);
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(device);
+    if (!guard.ok) { mif::set_error("mif_surf_create: cannot select device %d", device); return MIF_ERR_HIP; }
+    mif_surf* s = new mif_surf();
+    s->device = device; s->W = width; s->H = height; s->C = channels;
+    const int rc = surf_create_impl(s);
+    if (rc != MIF_OK) { surf_free(s); delete s; return rc; }
+    *out = s;
+    return MIF_OK;
+}
+
+int mif_surf_destroy(mif_surf* s)
+{
+    if (!s) return MIF_OK;
+    mif::DeviceGuard guard(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    surf_free(s);
+    delete s;
+    return MIF_OK;
+}
+
+int mif_surf_capacity(const mif_surf* s) { return s ? kMaxIpts : MIF_ERR_INVALID_ARGUMENT; }
+
+int mif_surf_enqueue(mif_surf* s, const void* d_pixels)
+{
+    if (!s || !d_pixels) { mif::set_error("mif_surf_enqueue: NULL argument"); return MIF_ERR_INVALID_ARGUMENT; }
+    mif::DeviceGuard guard(s->device);
+    return surf_enqueue(s, d_pixels);
+}
+
+int mif_surf_sync(mif_surf* s)
+{
+    if (!s) return MIF_ERR_INVALID_ARGUMENT;
+    mif::DeviceGuard guard(s->device);
+    MIF_HIP(hipStreamSynchronize(s->stream));
+    return MIF_OK;
+}
+
+void* mif_surf_stream(mif_surf* s) { return s ? (void*)s->stream : nullptr; }
+
+int mif_surf_device_results(mif_surf* s, void** d_pos, void** d_scale, void** d_laplacian, void** d_orientation,
+                            void** d_descriptors, void** d_counts)
+{
+    if (!s) return MIF_ERR_INVALID_ARGUMENT;
+    if (d_pos) *d_pos = s->pos;
+    if (d_scale) *d_scale = s->scale;
+    if (d_laplacian) *d_laplacian = s->lap;
+    if (d_orientation) *d_orientation = s->orient;
+    if (d_descriptors) *d_descriptors = s->desc;
+    if (d_counts) *d_counts = s->counts;
+    return MIF_OK;
+}
+
+int mif_surf_run(mif_surf* s, const uint8_t* pixels, mif_ipoint* points, int capacity, int* count, int* raw_count,
+                 float* elapsed_ms)
+{
+    if (!s || !pixels || !count || (capacity > 0 && !points)) {
+        mif::set_error("mif_surf_run: NULL argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(s->device);
+    *count = 0;
+    MIF_HIP(hipMemcpyAsync(s->d_pixels, pixels, (size_t)s->W * s->H * s->C, hipMemcpyHostToDevice, s->stream));
+    const int rc = surf_enqueue(s, s->d_pixels);
+    if (rc != MIF_OK) return rc;
+    MIF_HIP(hipMemcpyAsync(s->h_counts, s->counts, 2 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    MIF_HIP(hipStreamSynchronize(s->stream));
+    if (elapsed_ms) MIF_HIP(hipEventElapsedTime(elapsed_ms, s->ev0, s->ev1));
+    const int n = s->h_counts[0];
+    if (raw_count) *raw_count = s->h_counts[1];
+    if (n > capacity) {
+        mif::set_error("mif_surf_run: %d interest points do not fit capacity %d", n, capacity);
+        return MIF_ERR_CAPACITY;
+    }
+    if (n == 0) return MIF_OK;
+    s->h_f.resize((size_t)n * (2 + 1 + 1 + 64));
+    s->h_i.resize(n);
+    float* hpos = s->h_f.data();
+    float* hscale = hpos + 2 * (size_t)n;
+    float* hori = hscale + n;
+    float* hdesc = hori + n;
+    MIF_HIP(hipMemcpy(hpos, s->pos, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
+    MIF_HIP(hipMemcpy(hscale, s->scale, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    MIF_HIP(hipMemcpy(hori, s->orient, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    MIF_HIP(hipMemcpy(hdesc, s->desc, (size_t)n * 64 * sizeof(float), hipMemcpyDeviceToHost));
+    MIF_HIP(hipMemcpy(s->h_i.data(), s->lap, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        mif_ipoint& p = points[i];
+        p.x = hpos[2 * i]; p.y = hpos[2 * i + 1];
+        p.scale = hscale[i];
+        p.orientation = hori[i];
+        p.laplacian = s->h_i[i];
+        p.clusterIndex = 0;
+        memcpy(p.descriptor, hdesc + (size_t)i * 64, 64 * sizeof(float));
+    }
+    *count = n;
+    return MIF_OK;
+}
+
+int mif_surf_copy_integral(mif_surf* s, float* out)
+{
+    if (!s || !out) return MIF_ERR_INVALID_ARGUMENT;
+    mif::DeviceGuard guard(s->device);
+    MIF_HIP(hipStreamSynchronize(s->stream));
+    MIF_HIP(hipMemcpy(out, s->integral, (size_t)s->W * s->H * sizeof(float), hipMemcpyDeviceToHost));
+    return MIF_OK;
+}
+
+int mif_surf_layer_info(const mif_surf* s, int layer, int* width, int* height, int* step, int* filter)
+{
+    if (!s || layer < 0 || layer >= kLayers) return MIF_ERR_INVALID_ARGUMENT;
+    if (width) *width = s->tab.l[layer].w;
+    if (height) *height = s->tab.l[layer].h;
+    if (step) *step = s->tab.l[layer].step;
+    if (filter) *filter = s->tab.l[layer].filter;
+    return MIF_OK;
+}
+
+int mif_surf_copy_layer(mif_surf* s, int layer, float* responses, int32_t* laplacians)
+{
+    if (!s || layer < 0 || layer >= kLayers) return MIF_ERR_INVALID_ARGUMENT;
+    mif::DeviceGuard guard(s->device);
+    MIF_HIP(hipStreamSynchronize(s->stream));
+    const size_t n = (size_t)s->tab.l[layer].w * s->tab.l[layer].h;
+    if (n == 0) return MIF_OK;
+    if (responses)
+        MIF_HIP(hipMemcpy(responses, s->responses + s->tab.l[layer].off, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (laplacians)
+        MIF_HIP(hipMemcpy(laplacians, s->laplacians + s->tab.l[layer].off, n * sizeof(int), hipMemcpyDeviceToHost));
+    return MIF_OK;
+}
+
+} // extern "C"

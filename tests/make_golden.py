@@ -15,6 +15,7 @@ sys.path.insert(0, HERE)
 import oracle_lib as orc  # noqa: E402
 from synth import blob_image, dense_image  # noqa: E402
 
+SURF_CASES = ["box", "scene", "blob_bgr_200x150"]
 CASES = ["box", "scene", "blob_256x192", "blob_bgr_200x150", "dense_256x192", "blob_bgr_97x61"]
 
 
@@ -47,6 +48,16 @@ def main():
         print(name, img.shape, "rc", rc, "keypoints", [S.count(o) for o in range(3)],
               "raw", [S.raw_count(o) for o in range(3)])
     np.savez_compressed(os.path.join(orc.GOLDEN, "sift_golden.npz"), **out)
+    out = {}
+    for name in SURF_CASES:
+        img = load_case(name)
+        h, w = img.shape[:2]
+        S = orc.SurfOracle(w, h)
+        n = S.run(img)
+        out[name] = S.points()
+        out[name + "_intsum"] = S.integral().view(np.uint32).sum(dtype=np.uint64)
+        print("surf", name, img.shape, "points", n)
+    np.savez_compressed(os.path.join(orc.GOLDEN, "surf_golden.npz"), **out)
 
 
 if __name__ == "__main__":

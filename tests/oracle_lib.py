@@ -37,6 +37,20 @@ def lib():
         L.orc_math_atan2f.restype = C.c_float
         L.orc_match_top2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_match_top2.restype = C.c_int
+        L.orc_surf_create.restype = C.c_void_p
+        L.orc_surf_create.argtypes = [C.c_int, C.c_int]
+        L.orc_surf_destroy.argtypes = [C.c_void_p]
+        L.orc_surf_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_surf_count.argtypes = [C.c_void_p]
+        L.orc_surf_raw_count.argtypes = [C.c_void_p]
+        L.orc_surf_integral.argtypes = [C.c_void_p]
+        L.orc_surf_integral.restype = C.POINTER(C.c_float)
+        L.orc_surf_layer_info.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_int)] * 4
+        L.orc_surf_layer_responses.argtypes = [C.c_void_p, C.c_int]
+        L.orc_surf_layer_responses.restype = C.POINTER(C.c_float)
+        L.orc_surf_layer_laplacians.argtypes = [C.c_void_p, C.c_int]
+        L.orc_surf_layer_laplacians.restype = C.POINTER(C.c_int)
+        L.orc_surf_points.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_set_threads.argtypes = [C.c_int]
         L.orc_get_threads.restype = C.c_int
         _lib = L
@@ -158,3 +172,58 @@ def match_top2(q, db, dim=None):
         lib().orc_match_top2(q.ctypes.data, nq, db.ctypes.data if nd else None, nd, dim, ld,
                              idx.ctypes.data, dist.ctypes.data)
     return idx, dist
+
+
+class SurfOracle:
+    """One CPU run of the restated reference SURF pipeline."""
+
+    def __init__(self, width, height):
+        self.L = lib()
+        self.h = self.L.orc_surf_create(width, height)
+        if not self.h:
+            raise ValueError("bad image geometry")
+        self.width, self.height = width, height
+
+    def close(self):
+        if self.h:
+            self.L.orc_surf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def run(self, pixels):
+        px = np.ascontiguousarray(pixels, dtype=np.uint8)
+        ch = 1 if px.ndim == 2 else px.shape[2]
+        assert px.size == self.width * self.height * ch
+        return self.L.orc_surf_run(self.h, px.ctypes.data, ch)
+
+    def count(self):
+        return self.L.orc_surf_count(self.h)
+
+    def raw_count(self):
+        return self.L.orc_surf_raw_count(self.h)
+
+    def integral(self):
+        return _arr(self.L.orc_surf_integral(self.h), self.width * self.height).reshape(self.height, self.width)
+
+    def layer_info(self, i):
+        v = [C.c_int() for _ in range(4)]
+        self.L.orc_surf_layer_info(self.h, i, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)          # w, h, step, filter
+
+    def layer(self, i):
+        w, h, _, _ = self.layer_info(i)
+        if w * h == 0:
+            return np.zeros((h, w), np.float32), np.zeros((h, w), np.int32)
+        r = _arr(self.L.orc_surf_layer_responses(self.h, i), w * h).reshape(h, w)
+        l = np.ctypeslib.as_array(self.L.orc_surf_layer_laplacians(self.h, i), shape=(w * h,)).copy().reshape(h, w)
+        return r, l
+
+    def points(self):
+        """[N, 70] float32 rows: x, y, scale, orientation, laplacian, 0, descriptor[64]."""
+        n = self.count()
+        out = np.zeros((n, 70), np.float32)
+        if n:
+            self.L.orc_surf_points(self.h, out.ctypes.data)
+        return out

@@ -1,0 +1,87 @@
+"""GPU parity: the HIP SURF path (through the C ABI) against the CPU checker and the golden table.
+Bar: counts and laplacians exact, every fp32 output bit-identical (documented fallback tolerance of
+the reference's own comparison protocol, SURF/coopcl_surf/src/utils.cpp:127-185, is 0.1)."""
+import os
+
+import numpy as np
+import pytest
+
+import object_detection_amd as oda
+import oracle_lib as orc
+from make_golden import load_case
+from synth import blob_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare(img):
+    h, w = img.shape[:2]
+    c = 1 if img.ndim == 2 else 3
+    S = orc.SurfOracle(w, h)
+    n = S.run(img)
+    ex = oda.SurfExtractor(w, h, c)
+    pts, raw = ex.run(img)
+    assert len(pts) == n and raw == S.raw_count()
+    assert np.array_equal(ex.integral().view(np.uint32), S.integral().view(np.uint32))
+    for i in range(8):
+        assert ex.layer_info(i) == S.layer_info(i)
+        r_g, l_g = ex.layer(i)
+        r_o, l_o = S.layer(i)
+        assert np.array_equal(r_g.view(np.uint32), r_o.view(np.uint32)), i
+        assert np.array_equal(l_g, l_o), i
+    P = S.points()
+    if n:
+        assert np.array_equal(pts["x"].view(np.uint32), P[:, 0].view(np.uint32))
+        assert np.array_equal(pts["y"].view(np.uint32), P[:, 1].view(np.uint32))
+        assert np.array_equal(pts["scale"].view(np.uint32), P[:, 2].view(np.uint32))
+        assert np.array_equal(pts["laplacian"], P[:, 4].astype(np.int32))
+        assert np.array_equal(pts["orientation"].view(np.uint32), P[:, 3].view(np.uint32))
+        assert np.array_equal(pts["descriptor"].view(np.uint32), P[:, 6:].view(np.uint32))
+    return pts, P
+
+
+@pytest.mark.parametrize("name", ["box", "scene", "blob_bgr_200x150", "blob_256x192"])
+def test_surf_parity(name):
+    pts, P = _compare(load_case(name))
+    gold = np.load(os.path.join(orc.GOLDEN, "surf_golden.npz"))
+    if name in gold:
+        assert np.array_equal(pts["descriptor"], gold[name][:, 6:])
+
+
+@pytest.mark.parametrize("size", [(64, 64), (65, 47), (333, 129), (20, 20), (1, 1), (12, 300)])
+def test_surf_ragged_sizes(size):
+    w, h = size
+    _compare(blob_image(w, h, seed=w + 7 * h))
+
+
+def test_surf_flat_image_and_reuse():
+    ex = oda.SurfExtractor(256, 192)
+    pts, raw = ex.run(np.full((192, 256), 50, np.uint8))
+    assert len(pts) == 0 and raw == 0
+    img = blob_image(256, 192, seed=1)
+    S = orc.SurfOracle(256, 192)
+    S.run(img)
+    pts, _ = ex.run(img)
+    assert np.array_equal(pts["descriptor"].view(np.uint32), S.points()[:, 6:].view(np.uint32))
+
+
+def test_surf_module_interface_and_matching():
+    box, scene = load_case("box"), load_case("scene")
+    assert len(oda.surf.run(box)) == 0 or oda.surf._initialized      # empty until the driver is initialised
+    assert oda.surf.initialize_surf_driver([("ignored.cl", "scan")], offload=0.5)
+    a, b = oda.surf.run(box), oda.surf.run(scene)
+    Sa, Sb = orc.SurfOracle(324, 223), orc.SurfOracle(512, 384)
+    Sa.run(box), Sb.run(scene)
+    assert np.array_equal(a["descriptor"], Sa.points()[:, 6:]) and np.array_equal(b["descriptor"], Sb.points()[:, 6:])
+    m = oda.Matcher(len(a), len(b))
+    good, dist = oda.match_ratio_test(m, a["descriptor"], b["descriptor"])
+    idx_o, dist_o = orc.match_top2(Sa.points()[:, 6:], Sb.points()[:, 6:])
+    keep = dist_o[:, 0] < np.float32(0.75) * dist_o[:, 1]
+    assert np.array_equal(good[:, 0], np.nonzero(keep)[0]) and np.array_equal(good[:, 1], idx_o[keep, 0])
+    assert len(good) >= 5
+
+
+def test_surf_full_hd():
+    img = blob_image(1920, 1080, seed=1234, channels=3)
+    pts, P = _compare(img)
+    assert len(pts) > 1000
