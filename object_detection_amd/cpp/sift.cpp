@@ -1,0 +1,167 @@
+// SIFT:: host shims over the C ABI (see sift.h). One process-global pipeline,
+// rebuilt when the image geometry changes, like the reference's
+// `static std::unique_ptr<sift_algorithm> sift` (SIFT/sift.cpp:1992, 2148-2189).
+#include "sift.h"
+
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+
+#include "../../include/mi_features.h"
+
+namespace
+{
+    struct Global
+    {
+        mif_sift* handle = nullptr;
+        int width = 0, height = 0, depth = 0, device = 0;
+        std::vector<float> kp, ori, desc, probe;
+        ~Global() { mif_sift_destroy(handle); }
+    };
+
+    Global& g()
+    {
+        static Global inst;
+        return inst;
+    }
+
+    bool offload_ok(float offload) { return offload == -1.0f || (offload >= 0.0f && offload <= 1.0f); }
+
+    // SIFT::init, SIFT/sift.cpp:2148-2189
+    int init(const unsigned char* image, int width, int height, int depth, bool up_scale)
+    {
+        if (image == nullptr) {
+            std::cerr << "Load image failed, fixme!" << std::endl;
+            return MIF_ERR_INVALID_ARGUMENT;
+        }
+        Global& G = g();
+        if (G.handle == nullptr || width != G.width || height != G.height || depth != G.depth) {
+            std::cout << "Initialize ..." << std::endl;
+            mif_sift_destroy(G.handle);
+            G.handle = nullptr;
+            const int rc = mif_sift_create(G.device, width, height, depth, up_scale ? 1 : 0, &G.handle);
+            if (rc != MIF_OK) {
+                std::cerr << "SIFT: " << mif_last_error() << std::endl;
+                return rc;
+            }
+            G.width = width; G.height = height; G.depth = depth;
+            const size_t cap = (size_t)mif_sift_capacity(G.handle);
+            G.kp.resize(cap * 4);
+            G.ori.resize(cap);
+            G.desc.resize(cap * MIF_SIFT_DESC_DIM);
+            mif_sift_set_timing(G.handle, 1);
+        }
+        std::cout << "Execute ..." << std::endl;
+        return MIF_OK;
+    }
+
+    int run(size_t& elapsed_time, float offload, const unsigned char* image, int width, int height, int depth,
+            std::vector<SIFT::sfeature>& features, std::vector<float>* descriptors, std::vector<float>* orientations,
+            bool up_scale)
+    {
+        if (!offload_ok(offload)) return MIF_ERR_INVALID_ARGUMENT;
+        int rc = init(image, width, height, depth, up_scale);
+        if (rc != MIF_OK) return rc;
+        Global& G = g();
+        int counts[MIF_SIFT_OCTAVES] = {0, 0, 0};
+        float ms = 0.0f;
+        rc = mif_sift_extract(G.handle, image, G.kp.data(), descriptors ? G.ori.data() : nullptr,
+                              descriptors ? G.desc.data() : nullptr, mif_sift_capacity(G.handle), counts, &ms);
+        elapsed_time = (size_t)ms;
+        if (rc != MIF_OK) return rc;
+        // octave-major order, SIFT/sift.cpp:1889-1911
+        size_t row = 0;
+        for (int o = 0; o < MIF_SIFT_OCTAVES; o++)
+            for (int i = 0; i < counts[o]; i++, row++) {
+                SIFT::sfeature f{};
+                f.x = G.kp[4 * row + 0];
+                f.y = G.kp[4 * row + 1];
+                f.sigma = G.kp[4 * row + 2];
+                f.scale_id = (size_t)G.kp[4 * row + 3];
+                f.octave_id = (size_t)o;
+                features.push_back(f);
+            }
+        if (descriptors) {
+            descriptors->insert(descriptors->end(), G.desc.begin(), G.desc.begin() + row * MIF_SIFT_DESC_DIM);
+            orientations->insert(orientations->end(), G.ori.begin(), G.ori.begin() + row);
+        }
+        std::cout << "--------------------------------------------------------" << std::endl;
+        std::cout << "Elapsed_time_ms," << ms << std::endl;
+        std::cout << "--------------------------------------------------------" << std::endl;
+        return MIF_OK;
+    }
+
+    const float* probe(bool dog, float offload, const unsigned char* image, int width, int height, int depth, int oid,
+                       int sid)
+    {
+        std::vector<SIFT::sfeature> feats;
+        size_t ms = 0;
+        if (run(ms, offload, image, width, height, depth, feats, nullptr, nullptr, false) != MIF_OK) return nullptr;
+        Global& G = g();
+        int w = 0, h = 0;
+        if (mif_sift_octave_info(G.handle, oid, &w, &h, nullptr) != MIF_OK) return nullptr;
+        G.probe.assign((size_t)w * h, 0.0f);
+        const int rc = dog ? mif_sift_copy_dog(G.handle, 0, oid, sid, G.probe.data())
+                           : mif_sift_copy_level(G.handle, 0, oid, sid, G.probe.data());
+        return rc == MIF_OK ? G.probe.data() : nullptr;
+    }
+}
+
+namespace SIFT
+{
+    int extract_features(size_t& elapsed_time, float offload, const unsigned char* input_color_image, int width,
+                         int height, int color_depth, std::vector<sfeature>& features, bool up_scale)
+    {
+        return run(elapsed_time, offload, input_color_image, width, height, color_depth, features, nullptr, nullptr,
+                   up_scale);
+    }
+
+    int extract_features(size_t& elapsed_time, float offload, const unsigned char* input_color_image, int width,
+                         int height, int color_depth, std::vector<sfeature>& features,
+                         std::vector<float>& descriptors, std::vector<float>& orientations, bool up_scale)
+    {
+        return run(elapsed_time, offload, input_color_image, width, height, color_depth, features, &descriptors,
+                   &orientations, up_scale);
+    }
+
+    void store_task_exec_times(const std::string& path)
+    {
+        Global& G = g();
+        if (G.handle == nullptr) return;
+        float ms[MIF_SIFT_OCTAVES][MIF_SIFT_STAGES];
+        if (mif_sift_stage_times(G.handle, ms) != MIF_OK) return;
+        std::ofstream ofs(path + "sift_stage_times.csv");
+        if (!ofs.is_open()) {
+            std::cerr << "Couldn't open:\t" << path << "sift_stage_times.csv" << std::endl;
+            return;
+        }
+        static const char* names[MIF_SIFT_STAGES] = {"base_image", "scale_space", "detector", "orientation_descriptor"};
+        ofs << "octave,stage,gpu_ms" << std::endl;
+        for (int o = 0; o < MIF_SIFT_OCTAVES; o++)
+            for (int s = 0; s < MIF_SIFT_STAGES; s++) ofs << o << "," << names[s] << "," << ms[o][s] << std::endl;
+    }
+
+    size_t cnt_octaves() { return MIF_SIFT_OCTAVES; }
+    size_t cnt_scales() { return MIF_SIFT_LEVELS; }
+
+    const float* get_blur(float offload, const unsigned char* image, int width, int height, int color_depth, int oid,
+                          int sid)
+    {
+        return probe(false, offload, image, width, height, color_depth, oid, sid);
+    }
+
+    const float* get_diff_blur(float offload, const unsigned char* image, int width, int height, int color_depth,
+                               int oid, int sid)
+    {
+        return probe(true, offload, image, width, height, color_depth, oid, sid);
+    }
+
+    void set_device(int device)
+    {
+        Global& G = g();
+        if (device == G.device) return;
+        mif_sift_destroy(G.handle);
+        G.handle = nullptr;
+        G.device = device;
+    }
+}

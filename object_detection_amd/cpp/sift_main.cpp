@@ -1,0 +1,136 @@
+// demo_coopcl_sift: the command line of the reference's SIFT demo (SIFT/main.cpp) on the GPU path.
+//   -m object.pgm scene.pgm -f x   extract both, match, homography; report to stdout (+ -o report.json)
+//   -v frames -f x                 per-frame extraction and matching against the previous frame;
+//                                  frames = "file.raw:WxHxC" or a printf pattern of PGM/PPM files
+//   -i image -f x                  extract one image, print the feature count
+// -c (camera) needs a capture device and a display and is not available in this headless build.
+#include <chrono>
+#include <cstdio>
+#include <iostream>
+
+#include "kpmatch.h"
+#include "parse_args.h"
+#include "sift.h"
+
+static const bool up_scale = false;
+
+static std::string option(int argc, char** argv, const std::string& name)
+{
+    for (int i = 0; i + 1 < argc; i++)
+        if (name == argv[i]) return argv[i + 1];
+    return {};
+}
+
+// SIFT/main.cpp:176-206
+static int call_feature_match_demo(const std::string& object_path, const std::string& scene_path, float offload,
+                                   const std::string& report_path)
+{
+    auto frame_object = mif::imread(object_path, true);
+    auto frame_scene = mif::imread(scene_path, true);
+    if (frame_object.empty() || frame_scene.empty()) {
+        std::cerr << "Load image failed, fixme!" << std::endl;
+        return -1;
+    }
+    std::vector<SIFT::sfeature> feats_object, feats_scene;
+    std::vector<float> descs_object, descs_scene, orients_object, orients_scene;
+    size_t elapsed_time = 0;
+    int err = SIFT::extract_features(elapsed_time, offload, frame_object.data, frame_object.cols, frame_object.rows,
+                                     frame_object.channels(), feats_object, descs_object, orients_object, up_scale);
+    if (err != 0) return err;
+    std::cout << "feats_object:\t" << feats_object.size() << std::endl;
+    elapsed_time = 0;
+    err = SIFT::extract_features(elapsed_time, offload, frame_scene.data, frame_scene.cols, frame_scene.rows,
+                                 frame_scene.channels(), feats_scene, descs_scene, orients_scene, up_scale);
+    if (err != 0) return err;
+    std::cout << "feats_scene:\t" << feats_scene.size() << std::endl;
+
+    std::vector<fmatches::sift_feat> kp_object, kp_scene;
+    fmatches::ConvertToSift_feat<SIFT::sfeature>(feats_object, orients_object, descs_object, kp_object);
+    fmatches::ConvertToSift_feat<SIFT::sfeature>(feats_scene, orients_scene, descs_scene, kp_scene);
+    const auto report = fmatches::Plot_Img_Matches_ocv(frame_object, frame_scene, kp_object, kp_scene, up_scale);
+    if (report.has_homography) {
+        std::cout << "Homography inliers:\t" << report.inliers << std::endl;
+        for (int i = 0; i < 4; i++)
+            std::cout << "corner" << i << ":\t" << report.scene_corners[i].x << "\t" << report.scene_corners[i].y
+                      << std::endl;
+    }
+    if (!report_path.empty()) fmatches::write_report_json(report_path, report);
+    return 0;
+}
+
+// SIFT/main.cpp:103-153; each frame is also matched against the previous one
+static int call_stream_demo(const std::string& input, float offload)
+{
+    mif::FrameReader reader(input);
+    if (!reader.isOpened()) {
+        std::cerr << "Error opening video stream or file:\t" << input << std::endl;
+        return -1;
+    }
+    size_t acc_elapsed_time = 0, cnt_frames = 0, total_good = 0;
+    const size_t max_frames = 100;
+    std::vector<fmatches::sift_feat> prev;
+    mif::Image prev_frame;
+    const auto t0 = std::chrono::steady_clock::now();
+    while (cnt_frames < max_frames) {
+        mif::Image frame;
+        if (!reader.read(frame)) break;
+        std::vector<SIFT::sfeature> feats;
+        std::vector<float> descs, orients;
+        size_t elapsed_time = 0;
+        const int err = SIFT::extract_features(elapsed_time, offload, frame.data, frame.cols, frame.rows,
+                                               frame.channels(), feats, descs, orients, up_scale);
+        acc_elapsed_time += elapsed_time;
+        std::vector<fmatches::sift_feat> cur;
+        if (err == 0) fmatches::ConvertToSift_feat<SIFT::sfeature>(feats, orients, descs, cur);
+        std::cout << "Frame id<" << cnt_frames << "> Features: <" << cur.size() << ">" << std::endl;
+        if (!prev.empty() && !cur.empty())
+            total_good += fmatches::Plot_Img_Matches_ocv(frame, prev_frame, cur, prev, up_scale).good_matches.size();
+        prev.swap(cur);
+        prev_frame = frame;
+        cnt_frames++;
+    }
+    if (cnt_frames == 0) return -1;
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::cout << "Average time_ms:\t" << acc_elapsed_time / cnt_frames << std::endl;
+    std::cout << "Overall time_ms:\t" << acc_elapsed_time << std::endl;
+    std::cout << "Frames:\t" << cnt_frames << "\tgood matches:\t" << total_good << "\twall_ms:\t" << wall_ms << std::endl;
+    SIFT::store_task_exec_times("./");
+    return 0;
+}
+
+// SIFT/main.cpp:155-174
+static int call_single_img_demo(const std::string& path, float offload)
+{
+    auto frame = mif::imread(path, false);
+    if (frame.empty()) {
+        std::cerr << "Load image failed, fixme!" << std::endl;
+        return -1;
+    }
+    std::vector<SIFT::sfeature> feats;
+    std::vector<float> descs, orients;
+    size_t elapsed_time = 0;
+    const int err = SIFT::extract_features(elapsed_time, offload, frame.data, frame.cols, frame.rows, frame.channels(),
+                                           feats, descs, orients, up_scale);
+    if (err != 0) return err;
+    std::cout << "Features: <" << feats.size() << ">" << std::endl;
+    return 0;
+}
+
+int main(int argc, char** argv)
+{
+    iargs::app_args args;
+    if (!args.parse(argc, argv)) return iargs::app_args::usage(std::cerr);
+    const std::string report = option(argc, argv, "-o");
+    if (args.app_mode == "-h")
+        iargs::app_args::usage(std::cout);
+    else if (args.app_mode == "-i")
+        return call_single_img_demo(args.img_path_a, args.offload);
+    else if (args.app_mode == "-v")
+        return call_stream_demo(args.img_path_a, args.offload);
+    else if (args.app_mode == "-c") {
+        std::cerr << "Error opening video stream or file:\t(camera input is not available in this build)" << std::endl;
+        return -1;
+    } else if (args.app_mode == "-m")
+        return call_feature_match_demo(args.img_path_a, args.img_path_b, args.offload, report);
+    return 0;
+}

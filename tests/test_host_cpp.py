@@ -1,0 +1,97 @@
+"""The C++14 host layer (object_detection_amd/cpp): CPU unit tests of the compiled host code, and on the
+GPU the two demo programs against the Python path / the checker."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "object_detection_amd", "cpp", "build")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _need(binary):
+    path = os.path.join(BUILD, binary)
+    if not os.path.exists(path):
+        pytest.fail("%s missing: run `make -C object_detection_amd/cpp` (or __graft_entry__.build())" % path)
+    return path
+
+
+def test_host_layer_unit_tests(tmp_path):
+    out = subprocess.run([_need("test_host"), str(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "host tests passed" in out.stdout
+
+
+def test_demo_usage_and_argument_errors():
+    exe = _need("demo_coopcl_sift")
+    out = subprocess.run([exe, "-h"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "Usage" in out.stdout
+    out = subprocess.run([exe, "-m", "a.pgm", "b.pgm"], capture_output=True, text=True, timeout=60)   # no -f
+    assert "Usage" in out.stderr
+    out = subprocess.run([_need("demo_coopcl_Surf"), "-i", "x.pgm", "-f", "7"], capture_output=True, text=True, timeout=60)
+    assert "Usage" in out.stderr
+
+
+@pytest.mark.gpu
+def test_sift_match_demo_against_python_path(tmp_path):
+    import object_detection_amd as oda
+    import oracle_lib as orc
+    rep = str(tmp_path / "sift.json")
+    box, scene = os.path.join(GOLDEN, "box.pgm"), os.path.join(GOLDEN, "scene.pgm")
+    out = subprocess.run([_need("demo_coopcl_sift"), "-m", box, scene, "-f", "0", "-o", rep],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    a, b = orc.read_pnm(box), orc.read_pnm(scene)
+    _, fa = oda.SiftExtractor(a.shape[1], a.shape[0]).extract(a)
+    _, fb = oda.SiftExtractor(b.shape[1], b.shape[0]).extract(b)
+    assert "feats_object:\t%d" % len(fa.keypoints) in out.stdout
+    assert "feats_scene:\t%d" % len(fb.keypoints) in out.stdout
+    m = oda.Matcher(len(fa.descriptors), len(fb.descriptors))
+    matches, dist, mn, mx = oda.match_sift_features(m, fa.descriptors, fb.descriptors)
+    assert "Good matches: %d" % len(matches) in out.stdout
+    r = json.load(open(rep))
+    assert [g[:2] for g in r["good_matches"]] == matches.tolist()
+    assert r["has_homography"] and r["inliers"] >= 8
+    # the box lies inside the scene: its projected outline is a sane quadrilateral within the image margins
+    c = np.array(r["scene_corners"])
+    assert np.all(c[:, 0] > -100) and np.all(c[:, 0] < 612) and np.all(c[:, 1] > -100) and np.all(c[:, 1] < 484)
+    area = 0.5 * abs(np.dot(c[:, 0], np.roll(c[:, 1], 1)) - np.dot(c[:, 1], np.roll(c[:, 0], 1)))
+    assert 5000 < area < 120000
+
+
+@pytest.mark.gpu
+def test_surf_match_demo_against_checker(tmp_path):
+    import oracle_lib as orc
+    rep = str(tmp_path / "surf.json")
+    box, scene = os.path.join(GOLDEN, "box.pgm"), os.path.join(GOLDEN, "scene.pgm")
+    out = subprocess.run([_need("demo_coopcl_Surf"), "-m", box, scene, "-f", "1", "-o", rep],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    a, b = orc.read_pnm(box), orc.read_pnm(scene)
+    Sa, Sb = orc.SurfOracle(a.shape[1], a.shape[0]), orc.SurfOracle(b.shape[1], b.shape[0])
+    Sa.run(a), Sb.run(b)
+    assert "feats_object:\t%d" % Sa.count() in out.stdout and "feats_scene:\t%d" % Sb.count() in out.stdout
+    idx, dist = orc.match_top2(Sa.points()[:, 6:], Sb.points()[:, 6:])
+    keep = dist[:, 0] < np.float32(0.75) * dist[:, 1]
+    assert "Found stable matches:\t%d" % int(keep.sum()) in out.stdout
+    r = json.load(open(rep))
+    assert [g[:2] for g in r["good_matches"]] == np.stack([np.nonzero(keep)[0], idx[keep, 0]], 1).tolist()
+
+
+@pytest.mark.gpu
+def test_stream_demo_on_raw_frames(tmp_path):
+    from synth import blob_image
+    frames = [blob_image(320, 240, seed=5, channels=3, shift=(2 * t, t)) for t in range(4)]
+    raw = tmp_path / "clip.raw"
+    raw.write_bytes(b"".join(f.tobytes() for f in frames))
+    out = subprocess.run([_need("demo_coopcl_sift"), "-v", "%s:320x240x3" % raw, "-f", "0.3"],
+                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Average time_ms:" in out.stdout and "Frames:\t4" in out.stdout
+    assert os.path.exists(tmp_path / "sift_stage_times.csv")
+    out = subprocess.run([_need("demo_coopcl_Surf"), "-v", "%s:320x240x3" % raw, "-f", "0.3"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "Average elapsed_time:" in out.stdout
