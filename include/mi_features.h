@@ -198,6 +198,12 @@ int mif_match_destroy(mif_matcher* m);
  * distances dist2[2*i], dist2[2*i+1] (+inf when missing). */
 int mif_match_top2(mif_matcher* m, const float* q, int nq, const float* db, int nd, int dim, int ld,
                    int32_t* idx2, float* dist2);
+/* Same, and also returns the ranking scores of the two winners (squared-distance
+ * estimates |q|^2 + |d|^2 - 2 q.d, +inf when missing). Candidates of several
+ * database shards are merged on (score, index), which reproduces the result of
+ * one search over the whole database. score2 may be NULL. */
+int mif_match_top2_scores(mif_matcher* m, const float* q, int nq, const float* db, int nd, int dim, int ld,
+                          int32_t* idx2, float* dist2, float* score2);
 /* Device-resident form, enqueued on `stream` (a hipStream_t, NULL = default).
  * d_nq / d_nd, when not NULL, point to device int32 row counts that override
  * nq / nd (which then are the capacities the grid is sized for). */
@@ -220,6 +226,7 @@ typedef struct mif_match_pair {
     uint8_t* d_good;     /* [nq] 1 = kept by the filter */
     int32_t* d_summary;  /* {kept, query rows} */
     float* d_minmax;     /* {min_dist, max_dist} of the nearest distances (filter 1) */
+    float* d_score2;     /* [nq][2] ranking scores |q|^2 + |d|^2 - 2 q.d of the two winners, or NULL */
 } mif_match_pair;
 
 #define MIF_FILTER_NONE 0

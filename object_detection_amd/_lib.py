@@ -55,6 +55,7 @@ SYMBOLS = [
     ("mif_match_destroy", C.c_int, [_P]),
     ("mif_match_top2_batch_device", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("mif_match_top2", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    ("mif_match_top2_scores", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     ("mif_match_top2_device", C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P]),
 ]
 
@@ -62,7 +63,7 @@ SYMBOLS = [
 class MatchPair(C.Structure):
     """mif_match_pair of include/mi_features.h."""
     _fields_ = [("d_q", _P), ("d_db", _P), ("d_nq", _P), ("d_nd", _P), ("d_idx2", _P), ("d_dist2", _P),
-                ("d_good", _P), ("d_summary", _P), ("d_minmax", _P)]
+                ("d_good", _P), ("d_summary", _P), ("d_minmax", _P), ("d_score2", _P)]
 
 
 FILTER_NONE, FILTER_SIFT, FILTER_RATIO = 0, 1, 2

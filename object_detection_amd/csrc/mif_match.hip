@@ -271,12 +271,18 @@ __global__ void k_match_finalize(PairTable tbl, int nq_cap, int nd_cap, int dim,
     const float* q = Q + (size_t)i * ld;
     float e1 = (j1 >= 0) ? exact_dist(q, D + (size_t)j1 * ld, dim) : kInf;
     float e2 = (j2 >= 0) ? exact_dist(q, D + (size_t)j2 * ld, dim) : kInf;
+    float sc1 = (j1 >= 0) ? t.s1 : kInf, sc2 = (j2 >= 0) ? t.s2 : kInf;
     if (j2 >= 0 && (e2 < e1 || (e2 == e1 && j2 < j1))) {
         const float te = e1; e1 = e2; e2 = te;
         const int tj = j1; j1 = j2; j2 = tj;
+        const float ts = sc1; sc1 = sc2; sc2 = ts;
     }
     idx2[2 * i] = j1; idx2[2 * i + 1] = j2;
     dist2[2 * i] = e1; dist2[2 * i + 1] = e2;
+    if (pr.d_score2) {
+        pr.d_score2[2 * i] = sc1;
+        pr.d_score2[2 * i + 1] = sc2;
+    }
 }
 
 // Good-match filters of the reference on the device, one block per pair.
@@ -348,6 +354,7 @@ struct mif_matcher {
     size_t d_q_bytes = 0, d_db_bytes = 0;
     int* d_idx = nullptr;
     float* d_dist = nullptr;
+    float* d_score = nullptr;
 };
 
 namespace {
@@ -358,6 +365,7 @@ void free_matcher(mif_matcher* m)
 {
     (void)hipFree(m->qn); (void)hipFree(m->dn); (void)hipFree(m->part_s); (void)hipFree(m->part_i);
     (void)hipFree(m->d_q); (void)hipFree(m->d_db); (void)hipFree(m->d_idx); (void)hipFree(m->d_dist);
+    (void)hipFree(m->d_score);
 }
 
 int pick_split(int nq, int nd, int npairs, bool device_counts)
@@ -512,6 +520,12 @@ int mif_match_top2_device(mif_matcher* m, const float* d_q, int nq, const int32_
 int mif_match_top2(mif_matcher* m, const float* q, int nq, const float* db, int nd, int dim, int ld, int32_t* idx2,
                    float* dist2)
 {
+    return mif_match_top2_scores(m, q, nq, db, nd, dim, ld, idx2, dist2, nullptr);
+}
+
+int mif_match_top2_scores(mif_matcher* m, const float* q, int nq, const float* db, int nd, int dim, int ld,
+                          int32_t* idx2, float* dist2, float* score2)
+{
     if (!m || !idx2 || !dist2 || (nq > 0 && !q) || (nd > 0 && !db)) {
         mif::set_error("mif_match_top2: NULL argument");
         return MIF_ERR_INVALID_ARGUMENT;
@@ -537,17 +551,20 @@ int mif_match_top2(mif_matcher* m, const float* q, int nq, const float* db, int 
     if (!m->d_idx) {
         MIF_HIP(hipMalloc(&m->d_idx, (size_t)m->max_q * 2 * sizeof(int)));
         MIF_HIP(hipMalloc(&m->d_dist, (size_t)m->max_q * 2 * sizeof(float)));
+        MIF_HIP(hipMalloc(&m->d_score, (size_t)m->max_q * 2 * sizeof(float)));
     }
     MIF_HIP(hipMemcpy(m->d_q, q, qb, hipMemcpyHostToDevice));
     if (nd > 0) MIF_HIP(hipMemcpy(m->d_db, db, (size_t)nd * ld * sizeof(float), hipMemcpyHostToDevice));
     mif_match_pair pr;
     memset(&pr, 0, sizeof(pr));
     pr.d_q = m->d_q; pr.d_db = m->d_db; pr.d_idx2 = m->d_idx; pr.d_dist2 = m->d_dist;
+    pr.d_score2 = score2 ? m->d_score : nullptr;
     const int rc = match_batch(m, &pr, 1, nq, nd, dim, ld, 0, nullptr);
     if (rc != MIF_OK) return rc;
     MIF_HIP(hipDeviceSynchronize());
     MIF_HIP(hipMemcpy(idx2, m->d_idx, (size_t)nq * 2 * sizeof(int), hipMemcpyDeviceToHost));
     MIF_HIP(hipMemcpy(dist2, m->d_dist, (size_t)nq * 2 * sizeof(float), hipMemcpyDeviceToHost));
+    if (score2) MIF_HIP(hipMemcpy(score2, m->d_score, (size_t)nq * 2 * sizeof(float), hipMemcpyDeviceToHost));
     return MIF_OK;
 }
 

@@ -26,9 +26,10 @@ class Matcher:
     def __del__(self):
         self.close()
 
-    def top2(self, q, db, dim=None):
+    def top2(self, q, db, dim=None, return_scores=False):
         """q [nq, ld], db [nd, ld] float32 host arrays; only the first `dim` columns take part.
-        Returns idx [nq, 2] int32 (-1 = missing) and dist [nq, 2] float32 (inf = missing)."""
+        Returns idx [nq, 2] int32 (-1 = missing) and dist [nq, 2] float32 (inf = missing); with
+        return_scores also the ranking scores [nq, 2] used to merge database shards."""
         q = np.ascontiguousarray(q, np.float32)
         db = np.ascontiguousarray(db, np.float32)
         if q.ndim != 2 or db.ndim != 2 or (len(db) and q.shape[1] != db.shape[1]):
@@ -38,10 +39,12 @@ class Matcher:
         nq, nd = len(q), len(db)
         idx = np.full((nq, 2), -1, np.int32)
         dist = np.full((nq, 2), np.inf, np.float32)
+        score = np.full((nq, 2), np.inf, np.float32)
         if nq:
-            _lib.check(self._lib.mif_match_top2(self._h, q.ctypes.data, nq, db.ctypes.data if nd else None, nd,
-                                                dim, ld, idx.ctypes.data, dist.ctypes.data))
-        return idx, dist
+            _lib.check(self._lib.mif_match_top2_scores(self._h, q.ctypes.data, nq, db.ctypes.data if nd else None,
+                                                       nd, dim, ld, idx.ctypes.data, dist.ctypes.data,
+                                                       score.ctypes.data if return_scores else None))
+        return (idx, dist, score) if return_scores else (idx, dist)
 
     def top2_device(self, d_q, nq, d_db, nd, dim, ld, d_idx2, d_dist2, d_nq=None, d_nd=None, stream=None):
         """All pointers are integer device addresses; see mif_match_top2_device."""
@@ -60,6 +63,7 @@ class Matcher:
             a.d_nq, a.d_nd = p.get("nq"), p.get("nd")
             a.d_idx2, a.d_dist2 = p["idx2"], p["dist2"]
             a.d_good, a.d_summary, a.d_minmax = p.get("good"), p.get("summary"), p.get("minmax")
+            a.d_score2 = p.get("score2")
         _lib.check(self._lib.mif_match_top2_batch_device(self._h, arr, len(pairs), nq, nd, dim, ld, filter_mode,
                                                          C.c_void_p(stream) if stream else None))
 

@@ -50,8 +50,17 @@ float exact_dist(const float* q, const float* d, int dim)
 
 extern "C" {
 
-// Same contract as mif_match_top2 of include/mi_features.h.
+int orc_match_top2_scores(const float* q, int nq, const float* db, int nd, int dim, int ld, int32_t* idx2,
+                          float* dist2, float* score2);
+
 int orc_match_top2(const float* q, int nq, const float* db, int nd, int dim, int ld, int32_t* idx2, float* dist2)
+{
+    return orc_match_top2_scores(q, nq, db, nd, dim, ld, idx2, dist2, nullptr);
+}
+
+// Same contract as mif_match_top2_scores of include/mi_features.h.
+int orc_match_top2_scores(const float* q, int nq, const float* db, int nd, int dim, int ld, int32_t* idx2,
+                          float* dist2, float* score2)
 {
     const float inf = std::numeric_limits<float>::infinity();
     std::vector<float> dn((size_t)std::max(nd, 1)), dT((size_t)dim * std::max(nd, 1));
@@ -87,12 +96,15 @@ int orc_match_top2(const float* q, int nq, const float* db, int nd, int dim, int
             int j1 = t.i1 < nd ? t.i1 : -1, j2 = t.i2 < nd ? t.i2 : -1;
             float e1 = j1 >= 0 ? exact_dist(qr, db + (size_t)j1 * ld, dim) : inf;
             float e2 = j2 >= 0 ? exact_dist(qr, db + (size_t)j2 * ld, dim) : inf;
+            float s1 = j1 >= 0 ? t.s1 : inf, s2 = j2 >= 0 ? t.s2 : inf;
             if (j2 >= 0 && (e2 < e1 || (e2 == e1 && j2 < j1))) {
                 std::swap(e1, e2);
                 std::swap(j1, j2);
+                std::swap(s1, s2);
             }
             idx2[2 * i] = j1; idx2[2 * i + 1] = j2;
             dist2[2 * i] = e1; dist2[2 * i + 1] = e2;
+            if (score2) { score2[2 * i] = s1; score2[2 * i + 1] = s2; }
         }
     }
     return 0;

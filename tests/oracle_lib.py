@@ -37,6 +37,9 @@ def lib():
         L.orc_math_atan2f.restype = C.c_float
         L.orc_match_top2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_match_top2.restype = C.c_int
+        L.orc_match_top2_scores.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
+        L.orc_match_top2_scores.restype = C.c_int
         L.orc_surf_create.restype = C.c_void_p
         L.orc_surf_create.argtypes = [C.c_int, C.c_int]
         L.orc_surf_destroy.argtypes = [C.c_void_p]
@@ -159,8 +162,8 @@ class SiftOracle:
         return np.concatenate(kps), np.concatenate(octs), np.concatenate(ors), np.concatenate(des)
 
 
-def match_top2(q, db, dim=None):
-    """CPU statement of mif_match_top2 (same contract)."""
+def match_top2(q, db, dim=None, return_scores=False):
+    """CPU statement of mif_match_top2 / mif_match_top2_scores (same contract)."""
     q = np.ascontiguousarray(q, np.float32)
     db = np.ascontiguousarray(db, np.float32)
     ld = q.shape[1]
@@ -168,10 +171,11 @@ def match_top2(q, db, dim=None):
     nq, nd = len(q), len(db)
     idx = np.full((nq, 2), -1, np.int32)
     dist = np.full((nq, 2), np.inf, np.float32)
+    score = np.full((nq, 2), np.inf, np.float32)
     if nq:
-        lib().orc_match_top2(q.ctypes.data, nq, db.ctypes.data if nd else None, nd, dim, ld,
-                             idx.ctypes.data, dist.ctypes.data)
-    return idx, dist
+        lib().orc_match_top2_scores(q.ctypes.data, nq, db.ctypes.data if nd else None, nd, dim, ld,
+                                    idx.ctypes.data, dist.ctypes.data, score.ctypes.data)
+    return (idx, dist, score) if return_scores else (idx, dist)
 
 
 class SurfOracle:

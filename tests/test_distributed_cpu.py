@@ -1,0 +1,95 @@
+"""N > 1 host logic rehearsed on CPU: two gloo ranks shard a frame sequence and a descriptor database;
+the per-shard work is done by the CPU checker so that only the distributed plumbing is under test."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as orc
+    from object_detection_amd.distributed import ShardedDatabaseMatcher, shard_range
+    from synth import blob_image, sift_like_descriptors
+    orc.lib().orc_set_threads(2)
+
+    # database sharding: 1000 rows (not divisible by the world size on purpose with world = 3)
+    db = sift_like_descriptors(1001, 3)
+    q = sift_like_descriptors(157, 4)
+    db[700] = q[5]
+    db[10] = db[990] = q[9]          # a tie across two shards -> the lower global index wins
+    lo, hi = shard_range(len(db), rank, world)
+    sm = ShardedDatabaseMatcher(hi - lo, lo, local_top2=lambda a, b: orc.match_top2(a, b, return_scores=True))
+    idx, d = sm.match(q, db[lo:hi])
+    ref_idx, ref_d = orc.match_top2(q, db)
+    ok_match = bool(np.array_equal(idx, ref_idx) and np.array_equal(d.view(np.uint32), ref_d.view(np.uint32)))
+
+    # frame sharding: every rank extracts its block of a 6-frame sequence; counts are gathered for the check only
+    n_frames = 6
+    flo, fhi = shard_range(n_frames, rank, world)
+    counts = torch.zeros(n_frames, 3, dtype=torch.int64)
+    S = orc.SiftOracle(160, 120)
+    for t in range(flo, fhi):
+        S.run(blob_image(160, 120, seed=9, shift=(2 * t, t)), want_descriptors=False)
+        counts[t] = torch.tensor([S.count(o) for o in range(3)])
+    dist.all_reduce(counts)
+    np.save(os.path.join(out_dir, "r%d.npy" % rank), np.array([int(ok_match)] + counts.flatten().tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_gloo_sharding(world, tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    import oracle_lib as orc
+    from synth import blob_image
+    S = orc.SiftOracle(160, 120)
+    want = []
+    for t in range(6):
+        S.run(blob_image(160, 120, seed=9, shift=(2 * t, t)), want_descriptors=False)
+        want += [S.count(o) for o in range(3)]
+    for r in range(world):
+        got = np.load(tmp_path / ("r%d.npy" % r))
+        assert got[0] == 1, "rank %d: sharded match differs from the single search" % r
+        assert got[1:].tolist() == want
+
+
+def test_shard_range_and_merge_unit():
+    from object_detection_amd.distributed import merge_top2, shard_range
+    for n in (0, 1, 7, 16):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_range(n, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [b[1] - b[0] for b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    inf = float("inf")
+    scores = torch.tensor([[[1.0, 5.0]], [[1.0, 2.0]], [[inf, inf]]])        # 3 shards, 1 query
+    idx = torch.tensor([[[40, 41]], [[7, 90]], [[-1, -1]]], dtype=torch.int32)
+    dists = torch.tensor([[[1.0, 2.2]], [[1.0, 1.4]], [[inf, inf]]])
+    wi, wd = merge_top2(scores, idx, dists)
+    assert wi.tolist() == [[7, 40]] and wd.tolist() == [[1.0, 1.0]]           # score tie -> lower index first
+    scores = torch.tensor([[[3.0, inf]], [[inf, inf]]])
+    idx = torch.tensor([[[2, -1]], [[-1, -1]]], dtype=torch.int32)
+    dists = torch.tensor([[[1.7, inf]], [[inf, inf]]])
+    wi, wd = merge_top2(scores, idx, dists)
+    assert wi.tolist() == [[2, -1]] and wd[0, 0] == 1.7 and torch.isinf(wd[0, 1])

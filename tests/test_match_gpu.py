@@ -93,3 +93,31 @@ def test_large_parity_subset_and_property():
     idx2, dist2 = m.top2(q2, db2)
     assert np.array_equal(idx2[:, 0], perm2.astype(np.int32))      # exact copies come back with distance 0
     assert np.all(dist2[:, 0] == 0) and np.all(dist2[:, 1] > 0)
+
+
+def test_sharded_database_merge_equals_single_search():
+    """Database split into 3 shards searched separately on the GPU, candidates merged on (score, index):
+    identical to one search (what every rank computes after the all-gather in the multi-GPU path)."""
+    import torch
+    from object_detection_amd.distributed import ShardedDatabaseMatcher, merge_top2, shard_range
+    db = sift_like_descriptors(5003, 21)
+    q = sift_like_descriptors(700, 22)
+    db[4000] = q[5]
+    db[10] = db[4990] = q[9]
+    m = oda.Matcher(700, 5003)
+    ref_idx, ref_d, ref_s = m.top2(q, db, return_scores=True)
+    o_idx, o_d, o_s = orc.match_top2(q, db, return_scores=True)
+    assert np.array_equal(ref_idx, o_idx) and np.array_equal(ref_s.view(np.uint32), o_s.view(np.uint32))
+    S, I, D = [], [], []
+    for r in range(3):
+        lo, hi = shard_range(len(db), r, 3)
+        idx, d, s = m.top2(q, db[lo:hi], return_scores=True)
+        S.append(torch.from_numpy(s)); D.append(torch.from_numpy(d))
+        I.append(torch.from_numpy(np.where(idx >= 0, idx + lo, -1).astype(np.int32)))
+    wi, wd = merge_top2(torch.stack(S), torch.stack(I), torch.stack(D))
+    assert np.array_equal(wi.numpy(), ref_idx)
+    assert np.array_equal(wd.numpy().view(np.uint32), ref_d.view(np.uint32))
+    # the single-rank path of the wrapper (no process group) gives the same answer
+    sm = ShardedDatabaseMatcher(len(db), 0, max_query=700)
+    i1, d1 = sm.match(q, db)
+    assert np.array_equal(i1, ref_idx) and np.array_equal(d1.view(np.uint32), ref_d.view(np.uint32))
