@@ -599,6 +599,39 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ dog, siz
     }
 }
 
+// ------------------------------------------------------------------ gradients
+
+// Gradient magnitude and angle of pyramid levels 1..3, once per pixel. The
+// orientation and descriptor kernels of the reference recompute
+//   dx = L(y, x+1) - L(y, x-1),  dy = L(y-1, x) - L(y+1, x)   (sift.cpp:483-487; the
+//   descriptor uses dy with the opposite sign, sift.cpp:665-669)
+//   mag = sqrt(dx*dx + dy*dy),  theta = atan2(dy, dx)
+// for every sample of every keypoint window; windows overlap heavily, so the
+// values are computed here once and gathered there. Stored per pixel as
+// float2 {mag with the sign bit set iff dy != 0, theta of the orientation
+// kernel's convention}; the descriptor's angle atan2(-dy, dx) is -theta when
+// dy != 0 and theta when dy == 0 (mif_atan2f is odd in y except at y = 0), so
+// both kernels read back exactly the values they would have computed.
+// Border pixels are never sampled (windows are clipped to [1, w-2] x [1, h-2])
+// and are not written. grid (ceil(w/256), h, 3 levels x frames).
+__global__ __launch_bounds__(256) void k_gradient(const float* __restrict__ pyr, size_t pyr_stride,
+                                                  float2* __restrict__ grad, size_t grad_stride, int w, int h)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z / kIntervals;
+    const int l = blockIdx.z - f * kIntervals;            // 0..2 -> pyramid level l + 1
+    if (x < 1 || x > w - 2 || y < 1 || y > h - 2) return;
+    const size_t items = (size_t)w * h;
+    const float* img = pyr + (size_t)f * pyr_stride + (size_t)(l + 1) * items;
+    const float dx = img[y * w + x + 1] - img[y * w + x - 1];
+    const float dy = img[(y - 1) * w + x] - img[(y + 1) * w + x];
+    const float mag = __builtin_sqrtf(dx * dx + dy * dy);
+    const float theta = mif_atan2f(dy, dx);
+    const uint32_t mb = (mif_float_to_bits(mag) & 0x7fffffffu) | (dy != 0.0f ? 0x80000000u : 0u);
+    grad[(size_t)f * grad_stride + (size_t)l * items + (size_t)y * w + x] = make_float2(mif_bits_to_float(mb), theta);
+}
+
 // --------------------------------------------------------------- orientation
 
 // sift.cpp:431-582 kOrientation. A block serves four keypoints, 16 lanes each,
@@ -606,8 +639,8 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ dog, siz
 // l, l+16, ... into its private 36-bin histogram, the 16 histograms are summed
 // with the reference's tree (8, 4, 2, 1) and lane 0 smooths and picks the last
 // qualifying peak.
-__global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ kp, const float* __restrict__ pyr,
-                                                    size_t pyr_stride, int w, int h, int o, int cap,
+__global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ kp, const float2* __restrict__ grad,
+                                                    size_t grad_stride, int w, int h, int o, int cap,
                                                     const int* __restrict__ counts, float* __restrict__ orient)
 {
     __shared__ float s_hist[4][kOriLanes][kOriBins + 1];
@@ -615,7 +648,7 @@ __global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ k
     counts += (size_t)f * CNT_WORDS;
     kp += (size_t)f * cap;
     orient += (size_t)f * cap;
-    pyr += (size_t)f * pyr_stride;
+    grad += (size_t)f * grad_stride;
     const int grp = threadIdx.x >> 4;
     const int lid = threadIdx.x & 15;
     const int n = counts[CNT_OCT0 + o];
@@ -632,7 +665,9 @@ __global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ k
         const int rad = (int)mif_round(K_ORI_RADIUS * (double)f4.z);
         const float exp_factor = -0.5f / (exp_denom * exp_denom);
         const int sq_thres = rad * rad;
-        const int offset_py = (int)((float)(w * h) * f4.w);
+        // the reference offsets the pyramid by (int)(w*h*level) floats (sift.cpp:459); the
+        // gradient planes are stored from level 1 on
+        const int offset_py = (int)((float)(w * h) * f4.w) - w * h;
         const float p2o = mif_pow2i(o);
         const int x = (int)(f4.x / p2o);
         const int y = (int)(f4.y / p2o);
@@ -640,19 +675,18 @@ __global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ k
         const int xmax = min(w - 2, x + rad), ymax = min(h - 2, y + rad);
         const int wx = xmax - xmin + 1, hy = ymax - ymin + 1;
         const int loops = wx * hy;
-        const float* img = pyr + offset_py;
+        const float2* img = grad + offset_py;
         // window pixel i = (i / wx + ymin, i % wx + xmin), i = lid, lid + 16, ...
         int yy = lid / wx + ymin;
         int xx = lid % wx + xmin;
         for (int i = lid; i < loops; i += kOriLanes) {
             if (xx > 0 && xx < w - 1 && yy > 0 && yy < h - 1) {
-                float dx = img[yy * w + xx + 1] - img[yy * w + xx - 1];
-                float dy = img[(yy - 1) * w + xx] - img[(yy + 1) * w + xx];
                 const float ddx = (float)(xx - x), ddy = (float)(yy - y);
                 const int sq_dist = (int)(ddx * ddx + ddy * ddy);
                 if (sq_dist <= sq_thres) {
-                    const float grad = __builtin_sqrtf(dx * dx + dy * dy);
-                    const float theta = mif_atan2f(dy, dx);
+                    const float2 g2 = img[yy * w + xx];
+                    const float grad = mif_fabsf(g2.x);
+                    const float theta = g2.y;
                     int bin = (int)mif_round((kOriBins * ((double)theta + K_M_PI)) / K_M_PI2);
                     bin = (bin < kOriBins) ? bin : 0;
                     hist[bin] += grad * mif_expf((float)sq_dist * exp_factor);
@@ -722,7 +756,7 @@ __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fm
 // Normalisation sums the 128 squares sequentially, as the reference's
 // one-thread-per-keypoint kernel does.
 __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ kp, const float* __restrict__ orient,
-                                                    const float* __restrict__ pyr, size_t pyr_stride, int w, int h,
+                                                    const float2* __restrict__ grad, size_t grad_stride, int w, int h,
                                                     int o, int cap, const int* __restrict__ counts,
                                                     float* __restrict__ desc)
 {
@@ -735,7 +769,7 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
     kp += (size_t)f * cap;
     orient += (size_t)f * cap;
     desc += (size_t)f * cap * 128;
-    pyr += (size_t)f * pyr_stride;
+    grad += (size_t)f * grad_stride;
     const int n = counts[CNT_OCT0 + o];
     if ((int)blockIdx.x >= n) return;                  // uniform over the block
     const int gi = octave_base(counts, o) + blockIdx.x;
@@ -751,7 +785,7 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
     const float p2o = mif_pow2i(o);
     const int x = (int)(f4.x / p2o);
     const int y = (int)(f4.y / p2o);
-    const float* img = pyr + (int)((float)(w * h) * f4.w);
+    const float2* img = grad + ((int)((float)(w * h) * f4.w) - w * h);    // planes start at level 1
     const float ang = -orient[gi];
     const float spt = (float)fabs((double)f4.z * 3.0);
     float sn, cs;
@@ -784,14 +818,16 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
             const float ny = crspt * dy - srspt * dx;
             const float nxn = mif_fabsf(nx), nyn = mif_fabsf(ny);
             if (nxn < 1.0f && nyn < 1.0f) {
-                dx = img[yy * w + xx + 1] - img[yy * w + xx - 1];
-                dy = img[(yy + 1) * w + xx] - img[(yy - 1) * w + xx];
-                const float mod = __builtin_sqrtf(dx * dx + dy * dy);
-                float th = mif_atan2f(dy, dx);
+                const float2 g2 = img[yy * w + xx];
+                const float mod = mif_fabsf(g2.x);
+                // atan2(-dy, dx) from the stored atan2(dy, dx): sign bit of g2.x is set iff dy != 0
+                float th = (mif_float_to_bits(g2.x) >> 31) ? -g2.y : g2.y;
                 const float dnx = nx + offx, dny = ny + offy;
                 const float ww = mif_expf(-0.125f * (dnx * dnx + dny * dny));
-                const float wwx = (float)(1.0 - (double)nxn);
-                const float wwy = (float)(1.0 - (double)nyn);
+                // 1.0 - nxn is evaluated in double in the reference (sift.cpp:675-676); the
+                // difference is exact there, so rounding it to float equals the float subtraction
+                const float wwx = 1.0f - nxn;
+                const float wwy = 1.0f - nyn;
                 const float wgt = ww * wwx * wwy * mod;
                 th -= ang;
                 while (th < 0.0f) th = (float)((double)th + K_M_PI2);
@@ -864,6 +900,7 @@ struct OctaveBuf {
     float* base = nullptr;                 // [h][w] input of level 0
     float* pyr = nullptr;                  // [6][h][w]
     float* dog = nullptr;                  // [5][h][w]
+    float2* grad = nullptr;                // [3][h][w] gradient {mag, theta} of levels 1..3
     unsigned long long* mask = nullptr;    // [3*h][words]
     int* rowcnt = nullptr;                 // [3*h]
     int* rowoff = nullptr;                 // [3*h]
@@ -1006,11 +1043,14 @@ int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc
                                O.h, O.words, o, O.maxf, s->cap, (const int*)s->counts, s->kp);
             if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][3], st));
             if (want_desc) {
+                const size_t grad_stride = O.items * kIntervals;
+                hipLaunchKernelGGL(k_gradient, dim3((O.w + 255) / 256, O.h, kIntervals * nf), dim3(256), 0, st,
+                                   (const float*)O.pyr, pyr_stride, O.grad, grad_stride, O.w, O.h);
                 hipLaunchKernelGGL(k_orientation, dim3((O.maxf + 3) / 4, nf), dim3(64), 0, st, (const float4*)s->kp,
-                                   (const float*)O.pyr, pyr_stride, O.w, O.h, o, s->cap, (const int*)s->counts,
+                                   (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap, (const int*)s->counts,
                                    s->orient);
                 hipLaunchKernelGGL(k_descriptor, dim3(O.maxf, nf), dim3(128), 0, st, (const float4*)s->kp,
-                                   (const float*)s->orient, (const float*)O.pyr, pyr_stride, O.w, O.h, o, s->cap,
+                                   (const float*)s->orient, (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap,
                                    (const int*)s->counts, s->desc);
             }
         } else if (tm) {
@@ -1030,7 +1070,7 @@ void free_all(mif_sift* s)
 {
     for (int o = 0; o < kOctaves; o++) {
         OctaveBuf& O = s->oct[o];
-        (void)hipFree(O.base); (void)hipFree(O.pyr); (void)hipFree(O.dog);
+        (void)hipFree(O.base); (void)hipFree(O.pyr); (void)hipFree(O.dog); (void)hipFree(O.grad);
         (void)hipFree(O.mask); (void)hipFree(O.rowcnt); (void)hipFree(O.rowoff);
     }
     (void)hipFree(s->d_pixels); (void)hipFree(s->kp); (void)hipFree(s->orient);
@@ -1067,6 +1107,7 @@ int create_impl(mif_sift* s)
         MIF_HIP(hipMalloc(&O.base, B * O.items * sizeof(float)));
         MIF_HIP(hipMalloc(&O.pyr, B * O.items * kLevels * sizeof(float)));
         MIF_HIP(hipMalloc(&O.dog, B * O.items * (kLevels - 1) * sizeof(float)));
+        MIF_HIP(hipMalloc(&O.grad, B * O.items * kIntervals * sizeof(float2)));
         MIF_HIP(hipMalloc(&O.mask, B * O.rows * O.words * sizeof(unsigned long long)));
         MIF_HIP(hipMalloc(&O.rowcnt, B * O.rows * sizeof(int)));
         MIF_HIP(hipMalloc(&O.rowoff, B * O.rows * sizeof(int)));
