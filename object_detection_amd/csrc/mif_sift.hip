@@ -329,156 +329,146 @@ __device__ bool refine_pixel(const float* __restrict__ dp, const float* __restri
     return finish_pixel(r, cur, tx, ty, ts, o, out);
 }
 
-// Detection pass (sift.cpp:276-322, then the refinement). A block of 256
-// threads owns a 64 x 16 pixel tile of one frame.
-//  A. The five DoG images of the tile plus a one-pixel halo are staged in LDS
-//     (20 B read per pixel for all three detector levels).
-//  B. Every wave walks four consecutive rows, 64 pixels at a time, and tests
-//     border, |D| > 0.0108333 and the 3x3x3 extremum without branches; the few
-//     survivors are queued in LDS.
-//  C. The queue is dealt to the threads, one candidate each: first Newton step
-//     from the LDS tile, further steps (rare) from global memory; accepted
-//     candidates set their bit in the tile's acceptance bitmask.
-//  D. The tile's 3 x 16 bitmask words go to global memory and the row totals
-//     are accumulated with integer atomics (order independent).
-constexpr int kDetTW = 64, kDetTH = 16, kDetPitch = kDetTW + 2;
+// Detection pass (sift.cpp:276-322, then the refinement), streaming form
+// without a staging tile. A wave owns a strip of 62 columns (lanes 1..62; lanes
+// 0 and 63 only carry the neighbouring columns) and walks kDetRows rows of it.
+// Per row it loads one value per DoG image and lane (five coalesced 256-byte
+// loads, issued a group of rows ahead), obtains the left / right neighbours
+// from the adjacent lanes, and keeps the 3x3 neighbourhood of every image in
+// registers, sliding down one row at a time. The test is branch-free:
+// border, |D| > 0.0108333, and "v > every neighbour" evaluated as
+// v > max(neighbours) -- maxP leaves out (y-1, x+1), the position the
+// reference's test of the previous image never looks at (sift.cpp:299-301),
+// maxC leaves out the centre, max9 takes all nine; likewise for minima. The
+// few survivors are queued in LDS and refined one per thread; accepted
+// positions set their bit in the acceptance bitmask (cleared beforehand) and
+// bump the row total, both with integer atomics (order independent).
+constexpr int kDetCols = 62;        // output columns per wave
+constexpr int kDetRows = 32;        // rows per block
+constexpr int kDetGroup = 4;        // rows loaded ahead
+constexpr int kDetQueue = 4096;
 
 __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ dog, size_t dog_stride,
                                                 unsigned long long* __restrict__ mask, int* __restrict__ rowcnt,
                                                 int w, int h, int words, int o)
 {
-    constexpr int kTile = (kDetTH + 2) * kDetPitch;
-    __shared__ float s_d[kLevels - 1][kTile];
-    __shared__ int s_queue[kIntervals * kDetTW * kDetTH];
-    __shared__ unsigned long long s_mask[kIntervals][kDetTH];
+    __shared__ int s_queue[kDetQueue];
     __shared__ int s_ncand;
     const int f = blockIdx.z;
-    const int x0 = blockIdx.x * kDetTW, y0 = blockIdx.y * kDetTH;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int x = (blockIdx.x * 4 + wave) * kDetCols + lane - 1;
+    const int y0 = blockIdx.y * kDetRows;
     const size_t items = (size_t)w * h;
     dog += (size_t)f * dog_stride;
     if (threadIdx.x == 0) s_ncand = 0;
-    if (threadIdx.x < kIntervals * kDetTH) s_mask[threadIdx.x / kDetTH][threadIdx.x % kDetTH] = 0ull;
-    {
-        // all loads of a thread are issued before the first LDS store waits for one
-        constexpr int kIters = ((kLevels - 1) * kTile + 255) / 256;
-        float stage[kIters];
-#pragma unroll
-        for (int it = 0; it < kIters; it++) {
-            const int idx = threadIdx.x + it * 256;
-            const int l = idx / kTile;
-            const int rem = idx - l * kTile;
-            const int ly = rem / kDetPitch;
-            const int lx = rem - ly * kDetPitch;
-            const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-            float v = 0.0f;
-            if (idx < (kLevels - 1) * kTile && gx >= 0 && gx < w && gy >= 0 && gy < h)
-                v = dog[l * items + (size_t)gy * w + gx];
-            stage[it] = v;
-        }
-#pragma unroll
-        for (int it = 0; it < kIters; it++) {
-            const int idx = threadIdx.x + it * 256;
-            if (idx < (kLevels - 1) * kTile) (&s_d[0][0])[idx] = stage[it];
-        }
-    }
     __syncthreads();
-    // B. Per DoG image a lane keeps the 3x3 neighbourhood of its pixel in
-    // registers and slides it down one row at a time (3 LDS reads per image and
-    // row). "v > every neighbour" is evaluated as v > max(neighbours): maxP
-    // leaves out (y-1, x+1) -- the position the reference's test of the previous
-    // image never looks at (sift.cpp:299-301) -- maxC leaves out the centre, max9
-    // takes all nine; likewise for minima.
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int x = x0 + lane;
-    constexpr int kRowsPerWave = kDetTH / 4;
+    const bool xin = x >= 0 && x < w;
+    const bool xtest = lane >= 1 && lane <= kDetCols && x > kBorder && x < w - kBorder;
+    auto load_row = [&](int y, float v[kLevels - 1]) {
+        const bool ok = xin && y >= 0 && y < h;
+#pragma unroll
+        for (int l = 0; l < kLevels - 1; l++) v[l] = ok ? dog[l * items + (size_t)y * w + x] : 0.0f;
+    };
+    // nb[l][r][c]: rows r = 0..2 <-> y-1, y, y+1; columns c = 0..2 <-> x-1, x, x+1
     float nb[kLevels - 1][3][3];
-#pragma unroll
-    for (int l = 0; l < kLevels - 1; l++)
-#pragma unroll
-        for (int r = 1; r < 3; r++)
-#pragma unroll
-            for (int c = 0; c < 3; c++) nb[l][r][c] = s_d[l][(wave * kRowsPerWave + r - 1) * kDetPitch + lane + c];
-#pragma unroll
-    for (int rr = 0; rr < kRowsPerWave; rr++) {
-        const int ly = wave * kRowsPerWave + rr;
-        const int y = y0 + ly;
-        float maxP[3], minP[3], maxC[3], minC[3], max9[3], min9[3], cen[3];
+    auto push_row = [&](const float v[kLevels - 1]) {
 #pragma unroll
         for (int l = 0; l < kLevels - 1; l++) {
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 nb[l][0][c] = nb[l][1][c];
                 nb[l][1][c] = nb[l][2][c];
-                nb[l][2][c] = s_d[l][(ly + 2) * kDetPitch + lane + c];
             }
-            const float (*v)[3] = nb[l];
-            const float rmx0 = fmaxf(fmaxf(v[0][0], v[0][1]), v[0][2]), rmn0 = fminf(fminf(v[0][0], v[0][1]), v[0][2]);
-            const float rmx1 = fmaxf(fmaxf(v[1][0], v[1][1]), v[1][2]), rmn1 = fminf(fminf(v[1][0], v[1][1]), v[1][2]);
-            const float rmx2 = fmaxf(fmaxf(v[2][0], v[2][1]), v[2][2]), rmn2 = fminf(fminf(v[2][0], v[2][1]), v[2][2]);
-            if (l <= 2) {           // previous image of level l + 1
-                maxP[l] = fmaxf(fmaxf(fmaxf(v[0][0], v[0][1]), rmx1), rmx2);
-                minP[l] = fminf(fminf(fminf(v[0][0], v[0][1]), rmn1), rmn2);
-            }
-            if (l >= 1 && l <= 3) { // current image of level l
-                maxC[l - 1] = fmaxf(fmaxf(rmx0, fmaxf(v[1][0], v[1][2])), rmx2);
-                minC[l - 1] = fminf(fminf(rmn0, fminf(v[1][0], v[1][2])), rmn2);
-                cen[l - 1] = v[1][1];
-            }
-            if (l >= 2) {           // next image of level l - 1
-                max9[l - 2] = fmaxf(fmaxf(rmx0, rmx1), rmx2);
-                min9[l - 2] = fminf(fminf(rmn0, rmn1), rmn2);
-            }
+            // neighbouring lanes through DPP whole-wave shifts (no LDS traffic): wave_shr:1
+            // delivers lane i-1's value to lane i, wave_shl:1 lane i+1's; the end lanes,
+            // which receive nothing, are the two halo lanes whose results are not used
+            const int vi = __builtin_bit_cast(int, v[l]);
+            nb[l][2][0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x138, 0xf, 0xf, false));
+            nb[l][2][1] = v[l];
+            nb[l][2][2] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, vi, 0x130, 0xf, 0xf, false));
         }
-        const bool inside = y > kBorder && y < h - kBorder && x > kBorder && x < w - kBorder;
+    };
+    {
+        float v[kLevels - 1];
 #pragma unroll
-        for (int s = 1; s <= kIntervals; s++) {
-            const float cur = cen[s - 1];
-            const bool cand = inside && (double)mif_fabsf(cur) > K_CONTR_THR_1 &&
-                              ((cur > maxP[s - 1] && cur > maxC[s - 1] && cur > max9[s - 1]) ||
-                               (cur < minP[s - 1] && cur < minC[s - 1] && cur < min9[s - 1]));
-            if (cand) s_queue[atomicAdd(&s_ncand, 1)] = (s << 16) | (ly << 8) | lane;
-        }
+        for (int l = 0; l < kLevels - 1; l++)
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) nb[l][r][c] = 0.0f;
+        load_row(y0 - 1, v);
+        push_row(v);
+        load_row(y0, v);
+        push_row(v);
     }
-    __syncthreads();
-    // C. one candidate per thread
-    const int ncand = s_ncand;
-    for (int q = threadIdx.x; q < ncand; q += 256) {
-        const int e = s_queue[q];
-        const int s = e >> 16, ly = (e >> 8) & 0xff, lx = e & 0xff;
-        const float* P = s_d[s - 1] + (ly + 1) * kDetPitch + lx + 1;
-        const float* C = s_d[s] + (ly + 1) * kDetPitch + lx + 1;
-        const float* N = s_d[s + 1] + (ly + 1) * kDetPitch + lx + 1;
-        Stencil t;
-        t.c00 = C[0]; t.cxp = C[1]; t.cxm = C[-1]; t.cyp = C[kDetPitch]; t.cym = C[-kDetPitch];
-        t.cpp = C[kDetPitch + 1]; t.cmm = C[-kDetPitch - 1]; t.cpm = C[kDetPitch - 1]; t.cmp = C[-kDetPitch + 1];
-        t.n00 = N[0]; t.nxp = N[1]; t.nxm = N[-1]; t.nyp = N[kDetPitch]; t.nym = N[-kDetPitch];
-        t.p00 = P[0]; t.pxp = P[1]; t.pxm = P[-1]; t.pyp = P[kDetPitch]; t.pym = P[-kDetPitch];
-        const NewtonStep r = newton_step(t);
-        float4 kp;
-        bool found;
-        if (r.singular) {
-            found = false;
-        } else if (step_converged(r)) {
-            const float c1 = s == 1 ? P[0] : s == 2 ? C[0] : N[0];          // sift.cpp:400
-            found = finish_pixel(r, c1, x0 + lx, y0 + ly, s, o, &kp);
-        } else {
-            // has to move: repeat from global memory (the first step comes out identical)
-            found = refine_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o, x0 + lx,
-                                 y0 + ly, &kp);
+    // Rows are handled in groups; between groups the block drains the candidate
+    // queue when the next group could overflow it (a group adds at most
+    // kDetGroup x 4 x kDetCols x 3 entries) and once more at the end.
+    constexpr int kDrainAt = kDetQueue - kDetGroup * 4 * kDetCols * kIntervals;
+    static_assert(kDrainAt > 0, "candidate queue too small for one group of rows");
+    for (int g0 = 0;; g0 += kDetGroup) {
+        const bool done = g0 >= kDetRows || y0 + g0 >= h;      // uniform over the block
+        __syncthreads();
+        const int ncand = s_ncand;
+        if (done || ncand > kDrainAt) {
+            for (int q = threadIdx.x; q < ncand; q += 256) {
+                const int e = s_queue[q];
+                const int s = e >> 28;
+                const int y = y0 + ((e >> 16) & 0xfff);
+                const int cx = (e & 0xffff) - 1 + blockIdx.x * 4 * kDetCols;
+                float4 kp;
+                if (refine_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o, cx, y,
+                                 &kp)) {
+                    const size_t r = (size_t)f * kIntervals * h + (s - 1) * h + y;
+                    atomicOr(&mask[r * words + (cx >> 6)], 1ull << (cx & 63));
+                    atomicAdd(&rowcnt[r], 1);
+                }
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) s_ncand = 0;
+            __syncthreads();
         }
-        if (found) atomicOr(&s_mask[s - 1][ly], 1ull << lx);
-    }
-    __syncthreads();
-    // D.
-    if (threadIdx.x < kIntervals * kDetTH) {
-        const int s1 = threadIdx.x / kDetTH, ly = threadIdx.x % kDetTH;
-        const int y = y0 + ly;
-        if (y < h) {
-            const unsigned long long m = s_mask[s1][ly];
-            const size_t r = (size_t)f * kIntervals * h + s1 * h + y;
-            mask[r * words + blockIdx.x] = m;
-            if (m) atomicAdd(&rowcnt[r], __popcll(m));
+        if (done) break;
+        float ahead[kDetGroup][kLevels - 1];
+#pragma unroll
+        for (int g = 0; g < kDetGroup; g++) load_row(y0 + g0 + g + 1, ahead[g]);
+#pragma unroll
+        for (int g = 0; g < kDetGroup; g++) {
+            const int y = y0 + g0 + g;
+            push_row(ahead[g]);                             // window now centred on row y
+            float maxP[3], minP[3], maxC[3], minC[3], max9[3], min9[3], cen[3];
+#pragma unroll
+            for (int l = 0; l < kLevels - 1; l++) {
+                const float (*v)[3] = nb[l];
+                const float rmx0 = fmaxf(fmaxf(v[0][0], v[0][1]), v[0][2]), rmn0 = fminf(fminf(v[0][0], v[0][1]), v[0][2]);
+                const float rmx1 = fmaxf(fmaxf(v[1][0], v[1][1]), v[1][2]), rmn1 = fminf(fminf(v[1][0], v[1][1]), v[1][2]);
+                const float rmx2 = fmaxf(fmaxf(v[2][0], v[2][1]), v[2][2]), rmn2 = fminf(fminf(v[2][0], v[2][1]), v[2][2]);
+                if (l <= 2) {           // previous image of level l + 1
+                    maxP[l] = fmaxf(fmaxf(fmaxf(v[0][0], v[0][1]), rmx1), rmx2);
+                    minP[l] = fminf(fminf(fminf(v[0][0], v[0][1]), rmn1), rmn2);
+                }
+                if (l >= 1 && l <= 3) { // current image of level l
+                    maxC[l - 1] = fmaxf(fmaxf(rmx0, fmaxf(v[1][0], v[1][2])), rmx2);
+                    minC[l - 1] = fminf(fminf(rmn0, fminf(v[1][0], v[1][2])), rmn2);
+                    cen[l - 1] = v[1][1];
+                }
+                if (l >= 2) {           // next image of level l - 1
+                    max9[l - 2] = fmaxf(fmaxf(rmx0, rmx1), rmx2);
+                    min9[l - 2] = fminf(fminf(rmn0, rmn1), rmn2);
+                }
+            }
+            const bool inside = xtest && y > kBorder && y < h - kBorder;
+#pragma unroll
+            for (int s = 1; s <= kIntervals; s++) {
+                const float cur = cen[s - 1];
+                const bool cand = inside && (double)mif_fabsf(cur) > K_CONTR_THR_1 &&
+                                  ((cur > maxP[s - 1] && cur > maxC[s - 1] && cur > max9[s - 1]) ||
+                                   (cur < minP[s - 1] && cur < minC[s - 1] && cur < min9[s - 1]));
+                if (cand)
+                    s_queue[atomicAdd(&s_ncand, 1)] =
+                        (s << 28) | ((y - y0) << 16) | (x - (int)blockIdx.x * 4 * kDetCols + 1);
+            }
         }
     }
 }
@@ -613,23 +603,45 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ dog, siz
 // dy != 0 and theta when dy == 0 (mif_atan2f is odd in y except at y = 0), so
 // both kernels read back exactly the values they would have computed.
 // Border pixels are never sampled (windows are clipped to [1, w-2] x [1, h-2])
-// and are not written. grid (ceil(w/256), h, 3 levels x frames).
+// and are not written. A thread owns one column of four consecutive rows and
+// issues all 14 loads before the first use, which keeps enough bytes in flight
+// per wave to cover the HBM latency. grid (ceil(w/256), ceil(h/4), 3 levels x frames).
+constexpr int kGradRows = 4;
+
 __global__ __launch_bounds__(256) void k_gradient(const float* __restrict__ pyr, size_t pyr_stride,
                                                   float2* __restrict__ grad, size_t grad_stride, int w, int h)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
+    const int y0 = blockIdx.y * kGradRows;
     const int f = blockIdx.z / kIntervals;
     const int l = blockIdx.z - f * kIntervals;            // 0..2 -> pyramid level l + 1
-    if (x < 1 || x > w - 2 || y < 1 || y > h - 2) return;
+    if (x < 1 || x > w - 2) return;
     const size_t items = (size_t)w * h;
     const float* img = pyr + (size_t)f * pyr_stride + (size_t)(l + 1) * items;
-    const float dx = img[y * w + x + 1] - img[y * w + x - 1];
-    const float dy = img[(y - 1) * w + x] - img[(y + 1) * w + x];
-    const float mag = __builtin_sqrtf(dx * dx + dy * dy);
-    const float theta = mif_atan2f(dy, dx);
-    const uint32_t mb = (mif_float_to_bits(mag) & 0x7fffffffu) | (dy != 0.0f ? 0x80000000u : 0u);
-    grad[(size_t)f * grad_stride + (size_t)l * items + (size_t)y * w + x] = make_float2(mif_bits_to_float(mb), theta);
+    float2* out = grad + (size_t)f * grad_stride + (size_t)l * items;
+    float c[kGradRows + 2], lf[kGradRows], rt[kGradRows];
+#pragma unroll
+    for (int r = 0; r < kGradRows + 2; r++) {
+        const int y = min(max(y0 + r - 1, 0), h - 1);
+        c[r] = img[y * w + x];
+    }
+#pragma unroll
+    for (int r = 0; r < kGradRows; r++) {
+        const int y = min(y0 + r, h - 1);
+        lf[r] = img[y * w + x - 1];
+        rt[r] = img[y * w + x + 1];
+    }
+#pragma unroll
+    for (int r = 0; r < kGradRows; r++) {
+        const int y = y0 + r;
+        if (y < 1 || y > h - 2) continue;
+        const float dx = rt[r] - lf[r];
+        const float dy = c[r] - c[r + 2];
+        const float mag = __builtin_sqrtf(dx * dx + dy * dy);
+        const float theta = mif_atan2f(dy, dx);
+        const uint32_t mb = (mif_float_to_bits(mag) & 0x7fffffffu) | (dy != 0.0f ? 0x80000000u : 0u);
+        out[(size_t)y * w + x] = make_float2(mif_bits_to_float(mb), theta);
+    }
 }
 
 // --------------------------------------------------------------- orientation
@@ -1033,7 +1045,9 @@ int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc
         }
         if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][2], st));
         MIF_HIP(hipMemsetAsync(O.rowcnt, 0, (size_t)nf * O.rows * sizeof(int), st));
-        hipLaunchKernelGGL(k_detect, dim3(O.words, (O.h + kDetTH - 1) / kDetTH, nf), dim3(256), 0, st,
+        MIF_HIP(hipMemsetAsync(O.mask, 0, (size_t)nf * O.rows * O.words * sizeof(unsigned long long), st));
+        hipLaunchKernelGGL(k_detect, dim3((O.w + 4 * kDetCols - 1) / (4 * kDetCols), (O.h + kDetRows - 1) / kDetRows, nf),
+                           dim3(256), 0, st,
                            (const float*)O.dog, dog_stride, O.mask, O.rowcnt, O.w, O.h, O.words, o);
         hipLaunchKernelGGL(k_scan_rows, dim3(nf), dim3(1024), 0, st, (const int*)O.rowcnt, O.rowoff, O.rows, O.maxf,
                            o, s->counts);
@@ -1044,7 +1058,8 @@ int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc
             if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][3], st));
             if (want_desc) {
                 const size_t grad_stride = O.items * kIntervals;
-                hipLaunchKernelGGL(k_gradient, dim3((O.w + 255) / 256, O.h, kIntervals * nf), dim3(256), 0, st,
+                hipLaunchKernelGGL(k_gradient, dim3((O.w + 255) / 256, (O.h + kGradRows - 1) / kGradRows, kIntervals * nf),
+                                   dim3(256), 0, st,
                                    (const float*)O.pyr, pyr_stride, O.grad, grad_stride, O.w, O.h);
                 hipLaunchKernelGGL(k_orientation, dim3((O.maxf + 3) / 4, nf), dim3(64), 0, st, (const float4*)s->kp,
                                    (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap, (const int*)s->counts,
