@@ -32,6 +32,7 @@ constexpr int kInterpSteps = 5;    // _SIFT_MAX_INTERP_STEPS, sift.cpp:18
 constexpr int kOriBins = 36;       // _SIFT_ORI_HIST_BINS, sift.cpp:26
 constexpr int kOriLanes = 16;      // _SIFT_ORIENT_GPU_BLOCKSIZE, sift.cpp:27
 constexpr int kMaxTaps = 24;
+constexpr int kBlurTile = 64;      // output tile edge of the blur kernel
 
 // Kernel constants as the reference's kernels see them: the host prints them
 // into -D options with 6 significant digits and OpenCL C parses them as double
@@ -107,14 +108,22 @@ __global__ void k_decimate(const float* __restrict__ src, size_t src_stride, flo
 // short of the filter width, sift.cpp:222,238) in ascending order as an fmaf
 // chain starting from 0, with zeros outside the image.
 //
-// A block owns a TW x TH output tile. The (TW+2FR-1) x (TH+2FR-1) input window
-// is staged TRANSPOSED in LDS so that the horizontal pass can run with lanes
-// along y and a register sliding window along x (P outputs per work item),
-// and writes its result row-major so that the vertical pass runs with lanes
-// along x and a sliding window along y (R outputs per work item). Both passes
-// therefore read LDS with unit stride across lanes (conflict free) and touch
-// each staged value (P+2FR-1)/P resp. (R+2FR-1)/R times instead of 2FR times.
-template <int FR, int TW, int TH, bool DOG>
+// A block of 256 threads owns a 64 x 64 output tile and is bound by vector
+// instruction issue, not by LDS or HBM, so every phase is shaped to spend as
+// few instructions per pixel as possible:
+//  * staging: a wave takes one row of the (64+2FR-1)^2 input window per step
+//    (row index and bounds are wave-uniform, lanes run along x), issues all its
+//    loads before the first LDS store, and stores TRANSPOSED (odd pitch);
+//  * horizontal pass: lanes run along y; a thread owns rows r and r + H2 and an
+//    8-column chunk, keeps the 8+2FR-1 input pairs in registers and evaluates
+//    the two rows' chains side by side with packed FMAs (each half of a packed
+//    FMA is an IEEE fmaf, so the chains are the same as the scalar ones);
+//  * vertical pass: a thread owns two adjacent columns and 8 rows, reads the
+//    horizontal result as 8-byte pairs and again uses packed FMAs.
+// All LDS accesses of the passes have unit or odd lane stride.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int FR, bool DOG>
 __global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ src, size_t src_stride,
                                                     float* __restrict__ dst, float* __restrict__ dog,
                                                     size_t pyr_stride, size_t dog_stride, int w, int h, Taps taps)
@@ -122,82 +131,140 @@ __global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ sr
     src += (size_t)blockIdx.z * src_stride;
     dst += (size_t)blockIdx.z * pyr_stride;
     if (DOG) dog += (size_t)blockIdx.z * dog_stride;
+    constexpr int TW = kBlurTile, TH = kBlurTile;
     constexpr int P = 8, R = 8;
-    constexpr int EW = TW + 2 * FR - 1;          // staged columns
-    constexpr int EH = TH + 2 * FR - 1;          // staged rows
-    constexpr int PT = (EH % 2 == 0) ? EH + 1 : EH;   // odd pitch of the transposed input
-    constexpr int PH = TW + 1;                   // odd pitch of the H-pass result
     constexpr int NT = 2 * FR;                   // taps applied
-    static_assert(TW % P == 0 && TH % R == 0, "tile must be a multiple of the register windows");
-    static_assert(NT <= kMaxTaps, "too many taps");
+    constexpr int EW = TW + NT - 1;              // staged columns
+    constexpr int EH = TH + NT - 1;              // staged rows (odd)
+    constexpr int H2 = (EH + 1) / 2;             // a horizontal-pass thread owns rows r and r + H2
+    constexpr int PT = EH | 1;                   // odd pitch of the transposed input
+    constexpr int PH = TW + 2;                   // even pitch of the H-pass result (8-byte aligned pairs)
+    static_assert(TW == 64 && TH == 64, "thread mappings below assume a 64 x 64 tile");
+    static_assert(NT <= kMaxTaps && EW - 64 <= 64, "tap radius too large");
 
-    __shared__ float s_in[EW * PT];
-    __shared__ float s_h[EH * PH];
+    __shared__ float s_in[EW * PT + 1];          // + 1: the row r + H2 = EH of the last column is read, not used
+    __shared__ __align__(8) float s_h[EH * PH];
 
     const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int x0 = blockIdx.x * TW;
     const int y0 = blockIdx.y * TH;
 
-    // stage the input window, zero outside the image; all loads of a thread are
-    // issued before the first LDS store waits for one
+    // stage the input window, zero outside the image
     {
-        constexpr int kIters = (EW * EH + 255) / 256;
-        float stage[kIters];
+        constexpr int kSteps = (EH + 3) / 4;
+        const int gx0 = x0 - FR + lane, gx1 = gx0 + 64;
+        const bool in0 = gx0 >= 0 && gx0 < w;
+        const bool in1 = gx1 >= 0 && gx1 < w;
+        const int cx0 = min(max(gx0, 0), w - 1), cx1 = min(max(gx1, 0), w - 1);
+        float st0[kSteps], st1[kSteps];
 #pragma unroll
-        for (int it = 0; it < kIters; it++) {
-            const int idx = tid + it * 256;
-            const int ly = idx / EW;
-            const int lx = idx - ly * EW;
-            const int gx = x0 - FR + lx;
+        for (int it = 0; it < kSteps; it++) {
+            const int gy = min(max(y0 - FR + wv + 4 * it, 0), h - 1);
+            st0[it] = src[(size_t)gy * w + cx0];
+        }
+        if (lane < EW - 64) {
+#pragma unroll
+            for (int it = 0; it < kSteps; it++) {
+                const int gy = min(max(y0 - FR + wv + 4 * it, 0), h - 1);
+                st1[it] = src[(size_t)gy * w + cx1];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < kSteps; it++) {
+            const int ly = wv + 4 * it;
             const int gy = y0 - FR + ly;
-            float v = 0.0f;
-            if (idx < EW * EH && gx >= 0 && gx < w && gy >= 0 && gy < h) v = src[(size_t)gy * w + gx];
-            stage[it] = v;
+            const bool iny = gy >= 0 && gy < h;
+            if (ly < EH) s_in[lane * PT + ly] = (iny && in0) ? st0[it] : 0.0f;
         }
+        if (lane < EW - 64) {
 #pragma unroll
-        for (int it = 0; it < kIters; it++) {
-            const int idx = tid + it * 256;
-            const int ly = idx / EW;
-            const int lx = idx - ly * EW;
-            if (idx < EW * EH) s_in[lx * PT + ly] = stage[it];
-        }
-    }
-    __syncthreads();
-
-    // horizontal pass: lanes along the staged rows
-    for (int item = tid; item < EH * (TW / P); item += 256) {
-        const int chunk = item / EH;
-        const int row = item - chunk * EH;
-        float win[P + NT - 1];
-#pragma unroll
-        for (int j = 0; j < P + NT - 1; j++) win[j] = s_in[(chunk * P + j) * PT + row];
-#pragma unroll
-        for (int p = 0; p < P; p++) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int k = 0; k < NT; k++) acc = __builtin_fmaf(taps.t[k], win[p + k], acc);
-            s_h[row * PH + chunk * P + p] = acc;
+            for (int it = 0; it < kSteps; it++) {
+                const int ly = wv + 4 * it;
+                const int gy = y0 - FR + ly;
+                const bool iny = gy >= 0 && gy < h;
+                if (ly < EH) s_in[(64 + lane) * PT + ly] = (iny && in1) ? st1[it] : 0.0f;
+            }
         }
     }
     __syncthreads();
 
-    // vertical pass: lanes along x
-    for (int item = tid; item < TW * (TH / R); item += 256) {
-        const int yc = item / TW;
-        const int x = item - yc * TW;
-        float win[R + NT - 1];
+    // horizontal pass
+    for (int item = tid; item < (TW / P) * H2; item += 256) {
+        const int chunk = item / H2;
+        const int row = item - chunk * H2;
+        v2f win[P + NT - 1];
 #pragma unroll
-        for (int j = 0; j < R + NT - 1; j++) win[j] = s_h[(yc * R + j) * PH + x];
-        const int gx = x0 + x;
+        for (int j = 0; j < P + NT - 1; j++) {
+            const float* p = &s_in[(chunk * P + j) * PT + row];
+            win[j] = (v2f){p[0], p[H2]};
+        }
+        float* o0 = &s_h[row * PH + chunk * P];
+        const bool two = row + H2 < EH;
+        // the P chains advance together: consecutive packed FMAs are independent
+        v2f acc[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) acc[p] = (v2f){0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const v2f t = (v2f){taps.t[k], taps.t[k]};
+#pragma unroll
+            for (int p = 0; p < P; p++) acc[p] = __builtin_elementwise_fma(t, win[p + k], acc[p]);
+            __builtin_amdgcn_sched_barrier(0);      // keep the chains interleaved
+        }
+#pragma unroll
+        for (int p = 0; p < P; p++) o0[p] = acc[p].x;
+        if (two) {
+#pragma unroll
+            for (int p = 0; p < P; p++) o0[H2 * PH + p] = acc[p].y;
+        }
+    }
+    __syncthreads();
+
+    // vertical pass
+    {
+        const int xp = tid & 31;
+        const int yc = tid >> 5;
+        v2f win[R + NT - 1];
+#pragma unroll
+        for (int j = 0; j < R + NT - 1; j++) win[j] = *(const v2f*)&s_h[(yc * R + j) * PH + 2 * xp];
+        const int gx = x0 + 2 * xp;
+        const bool pair = gx + 1 < w && (w & 1) == 0;     // 8-byte aligned two-pixel stores
+        v2f acc[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[r] = (v2f){0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const v2f t = (v2f){taps.t[k], taps.t[k]};
+#pragma unroll
+            for (int r = 0; r < R; r++) acc[r] = __builtin_elementwise_fma(t, win[r + k], acc[r]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // pin the results here, or each chain is sunk into its row's bounds check below
+#pragma unroll
+        for (int r = 0; r < R; r++) asm volatile("" : "+v"(acc[r]));
 #pragma unroll
         for (int r = 0; r < R; r++) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int k = 0; k < NT; k++) acc = __builtin_fmaf(taps.t[k], win[r + k], acc);
             const int gy = y0 + yc * R + r;
-            if (gx < w && gy < h) {
-                dst[(size_t)gy * w + gx] = acc;
-                if (DOG) dog[(size_t)gy * w + gx] = acc - s_in[(x + FR) * PT + (yc * R + r + FR)];
+            if (gy < h && gx < w) {
+                const size_t at = (size_t)gy * w + gx;
+                v2f d = acc[r];
+                if (DOG) {
+                    const float* c = &s_in[(2 * xp + FR) * PT + (yc * R + r + FR)];
+                    d = acc[r] - (v2f){c[0], c[PT]};
+                }
+                if (pair) {
+                    *(v2f*)&dst[at] = acc[r];
+                    if (DOG) *(v2f*)&dog[at] = d;
+                } else {
+                    dst[at] = acc[r].x;
+                    if (DOG) dog[at] = d.x;
+                    if (gx + 1 < w) {
+                        dst[at + 1] = acc[r].y;
+                        if (DOG) dog[at + 1] = d.y;
+                    }
+                }
             }
         }
     }
@@ -980,14 +1047,13 @@ template <int FR>
 void launch_blur_fr(const float* src, size_t src_stride, float* dst, float* dog, size_t pyr_stride, size_t dog_stride,
                     int w, int h, int nframes, const Taps& t, hipStream_t st)
 {
-    constexpr int TW = 64, TH = 64;
-    dim3 grid((w + TW - 1) / TW, (h + TH - 1) / TH, nframes);
+    dim3 grid((w + kBlurTile - 1) / kBlurTile, (h + kBlurTile - 1) / kBlurTile, nframes);
     if (dog)
-        hipLaunchKernelGGL((k_blur_level<FR, TW, TH, true>), grid, dim3(256), 0, st, src, src_stride, dst, dog,
-                           pyr_stride, dog_stride, w, h, t);
+        hipLaunchKernelGGL((k_blur_level<FR, true>), grid, dim3(256), 0, st, src, src_stride, dst, dog, pyr_stride,
+                           dog_stride, w, h, t);
     else
-        hipLaunchKernelGGL((k_blur_level<FR, TW, TH, false>), grid, dim3(256), 0, st, src, src_stride, dst, dog,
-                           pyr_stride, dog_stride, w, h, t);
+        hipLaunchKernelGGL((k_blur_level<FR, false>), grid, dim3(256), 0, st, src, src_stride, dst, dog, pyr_stride,
+                           dog_stride, w, h, t);
 }
 
 int launch_blur(int fr, const float* src, size_t src_stride, float* dst, float* dog, size_t pyr_stride,
