@@ -88,6 +88,14 @@ def load_library():
             raise ImportError(
                 "%s is missing: build it with `make -C object_detection_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback" % path)
+        # PyTorch carries its own copy of the HIP runtime. A process that loads the system
+        # runtime first (through this library) and torch's afterwards ends up with two
+        # runtimes, and the second one finds no GPU; loading torch first makes this library
+        # bind to the runtime torch uses, whatever the caller's import order.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(path)
         for name, restype, argtypes in SYMBOLS:
             fn = getattr(lib, name)          # AttributeError if the ABI lacks a declared symbol

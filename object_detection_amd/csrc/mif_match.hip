@@ -23,9 +23,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kQT = 32;      // query rows per wave (one 32x32 MFMA tile)
 constexpr int kWaves = 4;    // waves per block, each with its own query tile
-constexpr int kDC = 32;      // database rows per staged chunk
+constexpr int kDC = 64;      // database rows per staged chunk (two MFMA tiles)
 constexpr float kInf = __builtin_inff();
 constexpr int kMaxPairs = 32;   // pairs per launch (the table travels as a kernel argument)
+
+__device__ const float c_zero = 0.0f;
 
 struct PairTable {
     mif_match_pair p[kMaxPairs];
@@ -70,16 +72,21 @@ __device__ __forceinline__ void top2_insert(Top2& t, float s, int i)
 
 // grid: (ceil(nq_cap / 128), nsplit, npairs). Wave v of block b owns query rows
 // [128 b + 32 v, +32); the block walks its share of the database in chunks of
-// 32 rows staged in LDS and shared by the four waves.
+// 64 rows (two 32-row MFMA tiles) staged in LDS and shared by the four waves.
 //
 // The queries are the B operand of the MFMA and live in registers for the whole
 // kernel: lane l holds q[query l&31][2 kk + (l>>5)] for kk = 0 .. KSTEPS-1. The
-// database chunk is the A operand, staged as s_b[half][row][kk] = d[row][2 kk +
-// half], so a lane fetches four k-steps with one ds_read_b128; rows are 16 B
-// apart modulo the bank row (pitch KSTEPS + 4), which keeps those reads
-// conflict free. The next
-// chunk's global loads are issued before the MFMA loop of the current chunk
-// and only waited for at the following LDS store.
+// database chunk is the A operand, staged as s_b[buf][half][row][kk] =
+// d[row][2 kk + half], so a lane fetches four k-steps with one ds_read_b128;
+// rows are 16 B apart modulo the bank row (pitch KSTEPS + 4), which keeps those
+// reads conflict free. The two tiles of a chunk give two independent
+// accumulation chains that are issued alternately.
+//
+// Pipeline per chunk, one barrier: registers -> LDS buffer (c & 1) | barrier |
+// issue the global loads of chunk c + 1 (not waited for until the next store) |
+// MFMA over buffer (c & 1) | top-2 update. Staging loads are unconditional (row
+// and column indices are clamped into the matrix, invalid values are replaced
+// at the LDS store), so nothing between the loads and the MFMA loop waits.
 template <int KSTEPS, bool VEC>
 __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int nq_cap, int nd_cap, int dim, int ld,
                                                        const float* __restrict__ qn, const float* __restrict__ dn,
@@ -88,9 +95,11 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int nq_cap
 {
     constexpr int K = 2 * KSTEPS;
     constexpr int KP = KSTEPS + 4;
-    constexpr int NV = K / 32;             // float4 (or 4 scalars) staged per thread and chunk
-    __shared__ __attribute__((aligned(16))) float s_b[2 * kDC * KP];
-    __shared__ __attribute__((aligned(16))) float s_dn[kDC];
+    constexpr int K4 = K / 4;                  // float4 per staged row
+    constexpr int NV = kDC * K4 / 256;         // float4 staged per thread and chunk
+    constexpr int RSTEP = 256 / K4;            // rows between a thread's consecutive float4
+    __shared__ __attribute__((aligned(16))) float s_b[2][2 * kDC * KP];
+    __shared__ __attribute__((aligned(16))) float s_dn[2][kDC];
     const mif_match_pair& pr = tbl.p[blockIdx.z];
     const float* __restrict__ Q = pr.d_q;
     const float* __restrict__ D = pr.d_db;
@@ -114,14 +123,17 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int nq_cap
     float qf[KSTEPS];
     const int qi = qbase + col;
     {
+        // elements outside the matrix are read from a zero word instead, so that every load is
+        // unconditional and all of them are in flight together
         const float* qr = Q + (size_t)min(qi, nq_cap - 1) * ld;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; kk++) {
             const int k = 2 * kk + half;
-            qf[kk] = (qi < nq && k < dim) ? qr[k] : 0.0f;
+            const float* p = (qi < nq && k < dim) ? qr + k : &c_zero;
+            qf[kk] = *p;
         }
     }
-    // The 32x32 result tile has the database row on the register index and the
+    // A 32x32 result tile has the database row on the register index and the
     // query on the lane: C[(reg&3) + 8 (reg>>2) + 4 half][col]. A lane therefore
     // keeps ONE running top-2 for its query; lanes l and l + 32 hold the same
     // query and are merged at the end.
@@ -135,84 +147,109 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int nq_cap
     const int c_lo = blockIdx.y * per;
     const int c_hi = min(chunks, c_lo + per);
 
+    // staging coordinates of this thread: float4 column k4 of rows r0, r0 + RSTEP, ...
+    const int k4 = tid % K4;
+    const int r0 = tid / K4;
+    const bool m0 = 4 * k4 + 0 < dim, m1 = 4 * k4 + 1 < dim, m2 = 4 * k4 + 2 < dim, m3 = 4 * k4 + 3 < dim;
+    const int kc0 = min(4 * k4 + 0, dim - 1), kc1 = min(4 * k4 + 1, dim - 1);
+    const int kc2 = min(4 * k4 + 2, dim - 1), kc3 = min(4 * k4 + 3, dim - 1);
+    const int k4c = m0 ? 4 * k4 : 0;           // a 16-byte load must start inside the row
+
     float4 stage[NV];
     float stage_dn = 0.0f;
     auto load_chunk = [&](int c) {
 #pragma unroll
         for (int it = 0; it < NV; it++) {
-            const int idx = tid + it * 256;
-            const int r = idx / (K / 4);
-            const int k4 = idx - r * (K / 4);
-            const int j = c * kDC + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < nd) {
-                const float* src = D + (size_t)j * ld + 4 * k4;
-                if (VEC) {
-                    if (4 * k4 < dim) v = *reinterpret_cast<const float4*>(src);
-                } else {
-                    if (4 * k4 + 0 < dim) v.x = src[0];
-                    if (4 * k4 + 1 < dim) v.y = src[1];
-                    if (4 * k4 + 2 < dim) v.z = src[2];
-                    if (4 * k4 + 3 < dim) v.w = src[3];
-                }
-                if (4 * k4 + 1 >= dim) v.y = 0.f;
-                if (4 * k4 + 2 >= dim) v.z = 0.f;
-                if (4 * k4 + 3 >= dim) v.w = 0.f;
+            const int j = min(c * kDC + r0 + RSTEP * it, nd - 1);
+            const float* src = D + (size_t)j * ld;
+            if (VEC) {
+                stage[it] = *reinterpret_cast<const float4*>(src + k4c);
+            } else {
+                stage[it] = make_float4(src[kc0], src[kc1], src[kc2], src[kc3]);
             }
-            stage[it] = v;
         }
-        if (tid < kDC) stage_dn = (c * kDC + tid < nd) ? dn[c * kDC + tid] : 0.0f;
+        stage_dn = dn[min(c * kDC + (tid & (kDC - 1)), nd - 1)];     // kept by the first kDC threads
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < NV; it++) {
-            const int idx = tid + it * 256;
-            const int r = idx / (K / 4);
-            const int k4 = idx - r * (K / 4);
+            const int r = r0 + RSTEP * it;
+            const float4 v = stage[it];
             // k = 4 k4 + {0, 2} -> half 0, kk = 2 k4 + {0, 1};  k = 4 k4 + {1, 3} -> half 1
-            *reinterpret_cast<float2*>(&s_b[(0 * kDC + r) * KP + 2 * k4]) = make_float2(stage[it].x, stage[it].z);
-            *reinterpret_cast<float2*>(&s_b[(1 * kDC + r) * KP + 2 * k4]) = make_float2(stage[it].y, stage[it].w);
+            *reinterpret_cast<float2*>(&s_b[buf][(0 * kDC + r) * KP + 2 * k4]) =
+                make_float2(m0 ? v.x : 0.0f, m2 ? v.z : 0.0f);
+            *reinterpret_cast<float2*>(&s_b[buf][(1 * kDC + r) * KP + 2 * k4]) =
+                make_float2(m1 ? v.y : 0.0f, m3 ? v.w : 0.0f);
         }
-        if (tid < kDC) s_dn[tid] = stage_dn;
+        if (tid < kDC) s_dn[buf][tid] = stage_dn;
     };
-
-    if (c_lo < c_hi) load_chunk(c_lo);
-    for (int c = c_lo; c < c_hi; c++) {
-        __syncthreads();                   // every wave is done reading the previous chunk
-        store_chunk();
-        __syncthreads();
-        if (c + 1 < c_hi) load_chunk(c + 1);
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
-        const float4* ap = reinterpret_cast<const float4*>(&s_b[(half * kDC + col) * KP]);
-#pragma unroll
-        for (int q4 = 0; q4 < KSTEPS / 4; q4++) {
-            const float4 a = ap[q4];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[4 * q4 + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[4 * q4 + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[4 * q4 + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[4 * q4 + 3], acc, 0, 0, 0);
-        }
-        // ascending database index within the lane: strict '<' keeps the lowest index on ties
+    // scores of one result tile against the running top-2; database indices ascend with the
+    // register index, and strict '<' keeps the lowest index on ties
+    auto consider = [&](const f32x16& acc, int jbase, const float* dnp, bool full) {
+        float sc[16];
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            const float4 dn4 = *reinterpret_cast<const float4*>(&s_dn[8 * g + 4 * half]);
-            const float dnr[4] = {dn4.x, dn4.y, dn4.z, dn4.w};
+            const float4 dn4 = *reinterpret_cast<const float4*>(&dnp[8 * g + 4 * half]);
+            sc[4 * g + 0] = __builtin_fmaf(-2.0f, acc[4 * g + 0], qnv + dn4.x);
+            sc[4 * g + 1] = __builtin_fmaf(-2.0f, acc[4 * g + 1], qnv + dn4.y);
+            sc[4 * g + 2] = __builtin_fmaf(-2.0f, acc[4 * g + 2], qnv + dn4.z);
+            sc[4 * g + 3] = __builtin_fmaf(-2.0f, acc[4 * g + 3], qnv + dn4.w);
+        }
+        if (!full) {
 #pragma unroll
-            for (int t = 0; t < 4; t++) {
-                const int j = c * kDC + 8 * g + 4 * half + t;
-                const float sc = __builtin_fmaf(-2.0f, acc[4 * g + t], qnv + dnr[t]);
-                if (j < nd) {
-                    if (sc < best.s1) {
-                        best.s2 = best.s1; best.i2 = best.i1;
-                        best.s1 = sc; best.i1 = j;
-                    } else if (sc < best.s2) {
-                        best.s2 = sc; best.i2 = j;
-                    }
+            for (int r = 0; r < 16; r++)
+                if (jbase + (r & 3) + 8 * (r >> 2) + 4 * half >= nd) sc[r] = kInf;
+        }
+        float mn = sc[0];
+#pragma unroll
+        for (int r = 1; r < 16; r++) mn = fminf(mn, sc[r]);
+        if (mn < best.s2) {                     // rare once the top-2 has settled
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int j = jbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (sc[r] < best.s1) {
+                    best.s2 = best.s1; best.i2 = best.i1;
+                    best.s1 = sc[r]; best.i1 = j;
+                } else if (sc[r] < best.s2) {
+                    best.s2 = sc[r]; best.i2 = j;
                 }
             }
         }
+    };
+
+    // one chunk of the pipeline; `buf` is a literal at both call sites so that every LDS
+    // access of the body is a fixed offset from loop-invariant addresses
+    auto chunk_step = [&](int c, int buf) {
+        store_chunk(buf);
+        // the buffer written here was last read two chunks ago, before the previous barrier
+        __syncthreads();
+        load_chunk(min(c + 1, c_hi - 1));      // unconditional: the last chunk is fetched twice
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        const float4* ap0 = reinterpret_cast<const float4*>(&s_b[buf][(half * kDC + col) * KP]);
+        const float4* ap1 = reinterpret_cast<const float4*>(&s_b[buf][(half * kDC + 32 + col) * KP]);
+#pragma unroll
+        for (int q4 = 0; q4 < KSTEPS / 4; q4++) {
+            const float4 a = ap0[q4];
+            const float4 b = ap1[q4];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qf[4 * q4 + 0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, qf[4 * q4 + 0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qf[4 * q4 + 1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, qf[4 * q4 + 1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qf[4 * q4 + 2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, qf[4 * q4 + 2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qf[4 * q4 + 3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, qf[4 * q4 + 3], acc1, 0, 0, 0);
+        }
+        const bool full = (c + 1) * kDC <= nd;
+        consider(acc0, c * kDC, &s_dn[buf][0], full);
+        consider(acc1, c * kDC + 32, &s_dn[buf][32], full);
+    };
+    if (c_lo < c_hi) load_chunk(c_lo);
+    for (int c = c_lo; c < c_hi; c += 2) {
+        chunk_step(c, 0);
+        if (c + 1 < c_hi) chunk_step(c + 1, 1);
     }
     // merge the two halves of the wave (same query, interleaved database rows)
     {
@@ -370,7 +407,7 @@ void free_matcher(mif_matcher* m)
 
 int pick_split(int nq, int nd, int npairs, bool device_counts)
 {
-    // Enough blocks to load every CU several times over, but no split shorter than 8 chunks.
+    // Enough blocks to load every CU several times over, but no split shorter than 4 chunks.
     // With device-side row counts nq / nd are capacities; the rows present are assumed to be
     // an eighth of them (blocks beyond the real counts exit at once).
     if (device_counts) {
@@ -380,7 +417,7 @@ int pick_split(int nq, int nd, int npairs, bool device_counts)
     const int qblocks = npairs * ((nq + kQT * kWaves - 1) / (kQT * kWaves));
     const int chunks = (nd + kDC - 1) / kDC;
     int split = (4096 + qblocks - 1) / qblocks;
-    split = std::min(split, std::max(1, chunks / 8));
+    split = std::min(split, std::max(1, chunks / 4));
     return std::max(1, std::min(split, kMaxSplit));
 }
 
