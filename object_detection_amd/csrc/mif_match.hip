@@ -33,8 +33,29 @@ struct PairTable {
     mif_match_pair p[kMaxPairs];
 };
 
-// grid (ceil(cap/256), npairs); which = 0: query rows, 1: database rows
-__global__ void k_row_norms(PairTable tbl, int which, int n_cap, int dim, int ld, float* __restrict__ out)
+// Loads `n` (<= 32) consecutive floats of a row into registers with as few
+// round trips to memory as possible: 16-byte loads when the row allows it.
+template <bool VEC>
+__device__ __forceinline__ void load_span(const float* __restrict__ r, int n, float (&v)[32])
+{
+    if (VEC && n == 32) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float4 t = reinterpret_cast<const float4*>(r)[i];
+            v[4 * i + 0] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 32; i++) v[i] = r[min(i, n - 1)];
+    }
+}
+
+// grid (ceil(cap/256), npairs); which = 0: query rows, 1: database rows.
+// A thread owns a row and walks it in spans of 32 elements: the loads of a span
+// are all in flight before the (strictly sequential) fmaf chain consumes them.
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_row_norms(PairTable tbl, int which, int n_cap, int dim, int ld,
+                                                   float* __restrict__ out)
 {
     const mif_match_pair& pr = tbl.p[blockIdx.y];
     const float* __restrict__ m = which ? pr.d_db : pr.d_q;
@@ -45,7 +66,16 @@ __global__ void k_row_norms(PairTable tbl, int which, int n_cap, int dim, int ld
     if (i >= n) return;
     const float* r = m + (size_t)i * ld;
     float acc = 0.0f;
-    for (int k = 0; k < dim; k++) acc = __builtin_fmaf(r[k], r[k], acc);
+    for (int k0 = 0; k0 < dim; k0 += 32) {
+        const int span = min(32, dim - k0);
+        // a 16-byte load may run past `dim` as long as it stays inside the row
+        const int avail = min(32, ld - k0);
+        float v[32];
+        load_span<VEC>(r + k0, avail, v);
+#pragma unroll
+        for (int k = 0; k < 32; k++)
+            if (k < span) acc = __builtin_fmaf(v[k], v[k], acc);
+    }
     out[i] = acc;
 }
 
@@ -265,19 +295,14 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int nq_cap
     }
 }
 
-__device__ __forceinline__ float exact_dist(const float* __restrict__ q, const float* __restrict__ d, int dim)
-{
-    float acc = 0.0f;
-    for (int k = 0; k < dim; k++) {
-        const float df = q[k] - d[k];
-        acc = __builtin_fmaf(df, df, acc);
-    }
-    return __builtin_sqrtf(acc);
-}
-
-// grid (ceil(nq_cap/128), npairs)
-__global__ void k_match_finalize(PairTable tbl, int nq_cap, int nd_cap, int dim, int ld, int nsplit,
-                                 const float* __restrict__ part_s, const int* __restrict__ part_i)
+// grid (ceil(nq_cap/128), npairs). A thread owns a query: it merges the splits'
+// candidates, then evaluates the exact distances of both winners together, one
+// span of 32 elements at a time (all loads of a span in flight, then the two
+// sequential fmaf chains).
+template <bool VEC>
+__global__ __launch_bounds__(128) void k_match_finalize(PairTable tbl, int nq_cap, int nd_cap, int dim, int ld,
+                                                        int nsplit, const float* __restrict__ part_s,
+                                                        const int* __restrict__ part_i)
 {
     const mif_match_pair& pr = tbl.p[blockIdx.y];
     const float* __restrict__ Q = pr.d_q;
@@ -300,26 +325,46 @@ __global__ void k_match_finalize(PairTable tbl, int nq_cap, int nd_cap, int dim,
     for (int sp = 0; sp < nsplit; sp++) {
         if (sp * per >= chunks) break;                  // this split had no database rows
         const size_t o = ((size_t)sp * nq_cap + i) * 2;
-        top2_insert(t, part_s[o], part_i[o]);
-        top2_insert(t, part_s[o + 1], part_i[o + 1]);
+        const float2 ps = *reinterpret_cast<const float2*>(&part_s[o]);
+        const int2 pi = *reinterpret_cast<const int2*>(&part_i[o]);
+        top2_insert(t, ps.x, pi.x);
+        top2_insert(t, ps.y, pi.y);
     }
     int j1 = (t.i1 < nd) ? t.i1 : -1;
     int j2 = (t.i2 < nd) ? t.i2 : -1;
     const float* q = Q + (size_t)i * ld;
-    float e1 = (j1 >= 0) ? exact_dist(q, D + (size_t)j1 * ld, dim) : kInf;
-    float e2 = (j2 >= 0) ? exact_dist(q, D + (size_t)j2 * ld, dim) : kInf;
+    // a missing winner is evaluated against row 0 (or the query itself) and discarded
+    const float* r1 = (j1 >= 0) ? D + (size_t)j1 * ld : q;
+    const float* r2 = (j2 >= 0) ? D + (size_t)j2 * ld : q;
+    float a1 = 0.0f, a2 = 0.0f;
+    for (int k0 = 0; k0 < dim; k0 += 32) {
+        const int span = min(32, dim - k0);
+        const int avail = min(32, ld - k0);
+        float vq[32], v1[32], v2[32];
+        load_span<VEC>(q + k0, avail, vq);
+        load_span<VEC>(r1 + k0, avail, v1);
+        load_span<VEC>(r2 + k0, avail, v2);
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            if (k < span) {
+                const float d1 = vq[k] - v1[k];
+                const float d2 = vq[k] - v2[k];
+                a1 = __builtin_fmaf(d1, d1, a1);
+                a2 = __builtin_fmaf(d2, d2, a2);
+            }
+        }
+    }
+    float e1 = (j1 >= 0) ? __builtin_sqrtf(a1) : kInf;
+    float e2 = (j2 >= 0) ? __builtin_sqrtf(a2) : kInf;
     float sc1 = (j1 >= 0) ? t.s1 : kInf, sc2 = (j2 >= 0) ? t.s2 : kInf;
     if (j2 >= 0 && (e2 < e1 || (e2 == e1 && j2 < j1))) {
         const float te = e1; e1 = e2; e2 = te;
         const int tj = j1; j1 = j2; j2 = tj;
         const float ts = sc1; sc1 = sc2; sc2 = ts;
     }
-    idx2[2 * i] = j1; idx2[2 * i + 1] = j2;
-    dist2[2 * i] = e1; dist2[2 * i + 1] = e2;
-    if (pr.d_score2) {
-        pr.d_score2[2 * i] = sc1;
-        pr.d_score2[2 * i + 1] = sc2;
-    }
+    *reinterpret_cast<int2*>(&idx2[2 * i]) = make_int2(j1, j2);
+    *reinterpret_cast<float2*>(&dist2[2 * i]) = make_float2(e1, e2);
+    if (pr.d_score2) *reinterpret_cast<float2*>(&pr.d_score2[2 * i]) = make_float2(sc1, sc2);
 }
 
 // Good-match filters of the reference on the device, one block per pair.
@@ -459,13 +504,23 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
         bool device_counts = false;
         for (int i = 0; i < np; i++) device_counts = device_counts || tbl.p[i].d_nq || tbl.p[i].d_nd;
         const int nsplit = pick_split(nq, nd, np, device_counts);
+        // 16-byte loads of rows need ld % 4 == 0 and 16-byte aligned row starts
+        bool vec_db = (ld % 4) == 0, vec_q = (ld % 4) == 0;
+        for (int i = 0; i < np; i++) {
+            vec_db = vec_db && ((reinterpret_cast<uintptr_t>(tbl.p[i].d_db) & 15u) == 0);
+            vec_q = vec_q && ((reinterpret_cast<uintptr_t>(tbl.p[i].d_q) & 15u) == 0);
+        }
         if (nd > 0) {
-            hipLaunchKernelGGL(k_row_norms, dim3((nd + 255) / 256, np), dim3(256), 0, st, tbl, 1, nd, dim, ld, dn);
-            hipLaunchKernelGGL(k_row_norms, dim3((nq + 255) / 256, np), dim3(256), 0, st, tbl, 0, nq, dim, ld, qn);
+            if (vec_db)
+                hipLaunchKernelGGL(k_row_norms<true>, dim3((nd + 255) / 256, np), dim3(256), 0, st, tbl, 1, nd, dim, ld, dn);
+            else
+                hipLaunchKernelGGL(k_row_norms<false>, dim3((nd + 255) / 256, np), dim3(256), 0, st, tbl, 1, nd, dim, ld, dn);
+            if (vec_q)
+                hipLaunchKernelGGL(k_row_norms<true>, dim3((nq + 255) / 256, np), dim3(256), 0, st, tbl, 0, nq, dim, ld, qn);
+            else
+                hipLaunchKernelGGL(k_row_norms<false>, dim3((nq + 255) / 256, np), dim3(256), 0, st, tbl, 0, nq, dim, ld, qn);
             dim3 grid((nq + kQT * kWaves - 1) / (kQT * kWaves), nsplit, np);
-            // 16-byte loads of database rows need ld % 4 == 0 and 16-byte aligned row starts
-            bool vec = (ld % 4) == 0;
-            for (int i = 0; i < np; i++) vec = vec && ((reinterpret_cast<uintptr_t>(tbl.p[i].d_db) & 15u) == 0);
+            const bool vec = vec_db;
 #define MIF_LAUNCH_PARTIAL(KS, V)                                                                             \
     hipLaunchKernelGGL((k_match_partial<KS, V>), grid, dim3(256), 0, st, tbl, nq, nd, dim, ld, (const float*)qn, \
                        (const float*)dn, nsplit, ps, pi)
@@ -473,8 +528,12 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
             else           { if (vec) MIF_LAUNCH_PARTIAL(64, true); else MIF_LAUNCH_PARTIAL(64, false); }
 #undef MIF_LAUNCH_PARTIAL
         }
-        hipLaunchKernelGGL(k_match_finalize, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim, ld,
-                           nsplit, (const float*)ps, (const int*)pi);
+        if (vec_db && vec_q)
+            hipLaunchKernelGGL(k_match_finalize<true>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim,
+                               ld, nsplit, (const float*)ps, (const int*)pi);
+        else
+            hipLaunchKernelGGL(k_match_finalize<false>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim,
+                               ld, nsplit, (const float*)ps, (const int*)pi);
         if (filter_mode != 0)
             hipLaunchKernelGGL(k_match_filter, dim3(np), dim3(256), 0, st, tbl, nq, filter_mode);
     }
