@@ -70,6 +70,16 @@ MIF_HD float mif_expf(float x)
     return mif_exp_poly(r) * mif_pow2i((int)n);
 }
 
+// mif_expf for callers that know -87 <= x <= 88: the same operations without the range
+// guards, hence the same result on that interval.
+MIF_HD float mif_expf_bounded(float x)
+{
+    const float n = __builtin_floorf(__builtin_fmaf(x, 1.44269504088896340736f, 0.5f));
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+    return mif_exp_poly(r) * mif_pow2i((int)n);
+}
+
 // 2^x for |x| < 126, about 1 ulp.
 MIF_HD float mif_exp2f(float x)
 {

@@ -53,6 +53,12 @@ struct Taps {
     float t[kMaxTaps];
 };
 
+// Thresholds of the orientation histogram: bin(theta) >= b exactly when theta >= t[b]
+// (t[0] = -inf, t[kOriBins + 1] = +inf), see build_ori_bins.
+struct OriBins {
+    float t[kOriBins + 2];
+};
+
 // counts[] layout in device memory
 enum { CNT_OCT0 = 0, CNT_TOTAL = 3, CNT_RAW0 = 4, CNT_STATUS = 7, CNT_WORDS = 8 };
 
@@ -69,16 +75,36 @@ __global__ void k_gray_u8(const uint8_t* __restrict__ in, float* __restrict__ ou
 }
 
 // sift.cpp:55-72 kColor_interleaved_ch
+__device__ __forceinline__ float gray_of_bgr(float b, float g, float r)
+{
+    const float cb = (float)0.114, cg = (float)0.587, cr = (float)0.299;
+    const float val_scale = (float)0.0039215686;
+    return (b * cb + g * cg + r * cr) * val_scale;
+}
+
 __global__ void k_gray_bgr(const uint8_t* __restrict__ in, float* __restrict__ out, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     in += (size_t)blockIdx.z * n * 3;
     out += (size_t)blockIdx.z * n;
-    const float b = (float)in[3 * i], g = (float)in[3 * i + 1], r = (float)in[3 * i + 2];
-    const float cb = (float)0.114, cg = (float)0.587, cr = (float)0.299;
-    const float val_scale = (float)0.0039215686;
-    out[i] = (b * cb + g * cg + r * cr) * val_scale;
+    out[i] = gray_of_bgr((float)in[3 * i], (float)in[3 * i + 1], (float)in[3 * i + 2]);
+}
+
+// Same conversion, four pixels per thread: 12 bytes come in as three 32-bit
+// words and a float4 goes out. Needs n % 4 == 0 and a 4-byte aligned frame.
+__global__ void k_gray_bgr_x4(const uint8_t* __restrict__ in, float* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // group of four pixels
+    if (4 * i >= n) return;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(in + (size_t)blockIdx.z * n * 3) + 3 * (size_t)i;
+    const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];      // B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+    float4 o;
+    o.x = gray_of_bgr((float)(w0 & 255u), (float)((w0 >> 8) & 255u), (float)((w0 >> 16) & 255u));
+    o.y = gray_of_bgr((float)(w0 >> 24), (float)(w1 & 255u), (float)((w1 >> 8) & 255u));
+    o.z = gray_of_bgr((float)((w1 >> 16) & 255u), (float)(w1 >> 24), (float)(w2 & 255u));
+    o.w = gray_of_bgr((float)((w2 >> 8) & 255u), (float)((w2 >> 16) & 255u), (float)(w2 >> 24));
+    reinterpret_cast<float4*>(out + (size_t)blockIdx.z * n)[i] = o;
 }
 
 // sift.cpp:113-132 kDown_pyramid with wo = 2w, d = 2, ss_img_id = 3
@@ -720,9 +746,12 @@ __global__ __launch_bounds__(256) void k_gradient(const float* __restrict__ pyr,
 // qualifying peak.
 __global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ kp, const float2* __restrict__ grad,
                                                     size_t grad_stride, int w, int h, int o, int cap,
-                                                    const int* __restrict__ counts, float* __restrict__ orient)
+                                                    const int* __restrict__ counts, float* __restrict__ orient,
+                                                    OriBins bins)
 {
     __shared__ float s_hist[4][kOriLanes][kOriBins + 1];
+    __shared__ float s_thr[kOriBins + 2];
+    if (threadIdx.x < kOriBins + 2) s_thr[threadIdx.x] = bins.t[threadIdx.x];
     const int f = blockIdx.y;
     counts += (size_t)f * CNT_WORDS;
     kp += (size_t)f * cap;
@@ -737,6 +766,7 @@ __global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ k
     const int gi = octave_base(counts, o) + g;
     float* hist = s_hist[grp][lid];
     for (int i = 0; i < kOriBins; i++) hist[i] = 0.0f;
+    __syncthreads();                                    // s_thr is complete
 
     if (active) {
         const float4 f4 = kp[gi];
@@ -756,23 +786,35 @@ __global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ k
         const int loops = wx * hy;
         const float2* img = grad + offset_py;
         // window pixel i = (i / wx + ymin, i % wx + xmin), i = lid, lid + 16, ...
-        int yy = lid / wx + ymin;
-        int xx = lid % wx + xmin;
+        // the window is clipped to [1, w-2] x [1, h-2], so every window pixel can be
+        // gathered; the next pixel's load is issued before the current one is processed
+        int yn = lid / wx + ymin;
+        int xn = lid % wx + xmin;
+        float2 gnext = (lid < loops) ? img[yn * w + xn] : make_float2(0.0f, 0.0f);
         for (int i = lid; i < loops; i += kOriLanes) {
+            const int xx = xn, yy = yn;
+            const float2 g2 = gnext;
+            xn += kOriLanes;
+            while (xn > xmax) { xn -= wx; yn++; }
+            if (i + kOriLanes < loops) gnext = img[yn * w + xn];
             if (xx > 0 && xx < w - 1 && yy > 0 && yy < h - 1) {
                 const float ddx = (float)(xx - x), ddy = (float)(yy - y);
                 const int sq_dist = (int)(ddx * ddx + ddy * ddy);
                 if (sq_dist <= sq_thres) {
-                    const float2 g2 = img[yy * w + xx];
                     const float grad = mif_fabsf(g2.x);
                     const float theta = g2.y;
-                    int bin = (int)mif_round((kOriBins * ((double)theta + K_M_PI)) / K_M_PI2);
+                    // bin = round(36 (theta + pi) / (2 pi)) in double (sift.cpp:493), a monotone
+                    // step function of theta: a float estimate that is off by at most one,
+                    // corrected against the exact thresholds
+                    int bin = min(max((int)__builtin_fmaf(theta, 5.72957795130823f, 18.5f), 0), kOriBins);
+                    bin += (theta >= s_thr[bin + 1]) ? 1 : 0;
+                    bin -= (theta < s_thr[bin]) ? 1 : 0;
                     bin = (bin < kOriBins) ? bin : 0;
-                    hist[bin] += grad * mif_expf((float)sq_dist * exp_factor);
+                    // sq_dist <= rad^2 with rad = round(4.5 sigma) and exp_factor = -0.5 / (1.5 sigma)^2:
+                    // the argument stays above -6
+                    hist[bin] += grad * mif_expf_bounded((float)sq_dist * exp_factor);
                 }
             }
-            xx += kOriLanes;
-            while (xx > xmax) { xx -= wx; yy++; }
         }
     }
     __syncthreads();
@@ -888,38 +930,57 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
     const int loops = (wx > 0 && hy > 0) ? wx * hy : 0;
     if (loops > 0) {
         // window pixel i = (i / wx + ymin, i % wx + xmin), i = lid, lid + 8, ...
-        int yy = lid / wx + ymin;
-        int xx = lid % wx + xmin;
+        // The gather of the next window pixel is issued before the current one is
+        // processed (whether or not it will pass the cell test), so its latency overlaps
+        // the arithmetic.
+        int yn = lid / wx + ymin;
+        int xn = lid % wx + xmin;
+        float2 gnext = (lid < loops) ? img[yn * w + xn] : make_float2(0.0f, 0.0f);
         for (int i = lid; i < loops; i += 8) {
+            const int xx = xn, yy = yn;
+            const float2 g2 = gnext;
+            xn += 8;
+            while (xn > xmax) { xn -= wx; yn++; }
+            if (i + 8 < loops) gnext = img[yn * w + xn];
             float dx = (float)xx - ptx;
             float dy = (float)yy - pty;
             const float nx = crspt * dx + srspt * dy;
             const float ny = crspt * dy - srspt * dx;
             const float nxn = mif_fabsf(nx), nyn = mif_fabsf(ny);
             if (nxn < 1.0f && nyn < 1.0f) {
-                const float2 g2 = img[yy * w + xx];
                 const float mod = mif_fabsf(g2.x);
                 // atan2(-dy, dx) from the stored atan2(dy, dx): sign bit of g2.x is set iff dy != 0
                 float th = (mif_float_to_bits(g2.x) >> 31) ? -g2.y : g2.y;
                 const float dnx = nx + offx, dny = ny + offy;
-                const float ww = mif_expf(-0.125f * (dnx * dnx + dny * dny));
+                // |dnx|, |dny| < 2.5 here, so the argument lies in (-1.6, 0]
+                const float ww = mif_expf_bounded(-0.125f * (dnx * dnx + dny * dny));
                 // 1.0 - nxn is evaluated in double in the reference (sift.cpp:675-676); the
                 // difference is exact there, so rounding it to float equals the float subtraction
                 const float wwx = 1.0f - nxn;
                 const float wwy = 1.0f - nyn;
                 const float wgt = ww * wwx * wwy * mod;
                 th -= ang;
-                while (th < 0.0f) th = (float)((double)th + K_M_PI2);
-                while ((double)th >= K_M_PI2) th = (float)((double)th - K_M_PI2);
+                // The reference wraps with two loops in double, `while (th < 0) th += 2 pi` and
+                // `while (th >= 2 pi) th -= 2 pi`. |theta| and |ang| are at most float(pi), so
+                // th lies in [-2 float(pi), 2 float(pi)]: the first loop runs at most twice
+                // (float(pi) > pi) and the second at most once. (double)th >= 2 pi holds exactly
+                // when th >= float(2 pi), the smallest float above 2 pi, so that test needs no
+                // conversion; 64-bit operations are slow on this GPU.
+                if (th < 0.0f) {
+                    th = (float)((double)th + K_M_PI2);
+                    if (th < 0.0f) th = (float)((double)th + K_M_PI2);
+                }
+                if (th >= 6.2831854820251465f) {
+                    th = (float)((double)th - K_M_PI2);
+                    if (th >= 6.2831854820251465f) th = (float)((double)th - K_M_PI2);
+                }
                 const float tth = (float)((double)th * K_RPI);
                 const int fo0 = (int)__builtin_floorf(tth);
                 const float do0 = tth - (float)fo0;
-                const int fo = fo0 % 8;
+                const int fo = fo0 & 7;             // fo0 is in 0..8; same as the reference's % 8
                 d[fo] += (1.0f - do0) * wgt;
                 d[fo + 1] += do0 * wgt;
             }
-            xx += 8;
-            while (xx > xmax) { xx -= wx; yy++; }
         }
     }
     d[0] += d[8];
@@ -1019,6 +1080,32 @@ void build_taps(std::vector<float> taps[kLevels], int fr[kLevels])
     }
 }
 
+// Orientation bin of an angle exactly as the kernel of the reference computes it
+// (sift.cpp:493, before the wrap of bin 36 to 0).
+int ori_bin_of(float theta)
+{
+    return (int)mif_round((kOriBins * ((double)theta + K_M_PI)) / K_M_PI2);
+}
+
+// ori_bin_of is monotone in theta, so it is fully described by the smallest float that
+// reaches each bin; they are found by bisection over the ordered bit patterns of
+// [-float(pi), float(pi)], the range of the stored angles.
+void build_ori_bins(OriBins* out)
+{
+    auto key_of = [](float f) { uint32_t u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+    auto float_of = [](uint32_t k) { uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &u, 4); return f; };
+    out->t[0] = -INFINITY;
+    out->t[kOriBins + 1] = INFINITY;
+    for (int b = 1; b <= kOriBins; b++) {
+        uint32_t lo = key_of(-MIF_PI_F), hi = key_of(MIF_PI_F);      // bin(lo) = 0 < b <= 36 = bin(hi)
+        while (hi - lo > 1) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (ori_bin_of(float_of(mid)) >= b) hi = mid; else lo = mid;
+        }
+        out->t[b] = float_of(hi);
+    }
+}
+
 } // namespace
 
 struct mif_sift {
@@ -1035,6 +1122,7 @@ struct mif_sift {
     std::vector<float> taps[kLevels];
     int fr[kLevels];
     Taps ktaps[kLevels];
+    OriBins ori_bins;
     bool frame_done = false;
     // optional per-stage timing: events at the stage boundaries of every octave
     bool timing = false, timed_frame = false, timed_desc = false;
@@ -1087,7 +1175,10 @@ int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc
         const size_t pyr_stride = O.items * kLevels, dog_stride = O.items * (kLevels - 1);
         if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][0], st));
         if (o == 0) {
-            if (s->C == 3)
+            if (s->C == 3 && items % 4 == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 3u) == 0)
+                hipLaunchKernelGGL(k_gray_bgr_x4, dim3((items / 4 + 255) / 256, 1, nf), dim3(256), 0, st,
+                                   (const uint8_t*)d_pixels, O.base, items);
+            else if (s->C == 3)
                 hipLaunchKernelGGL(k_gray_bgr, dim3((items + 255) / 256, 1, nf), dim3(256), 0, st,
                                    (const uint8_t*)d_pixels, O.base, items);
             else
@@ -1129,7 +1220,7 @@ int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc
                                    (const float*)O.pyr, pyr_stride, O.grad, grad_stride, O.w, O.h);
                 hipLaunchKernelGGL(k_orientation, dim3((O.maxf + 3) / 4, nf), dim3(64), 0, st, (const float4*)s->kp,
                                    (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap, (const int*)s->counts,
-                                   s->orient);
+                                   s->orient, s->ori_bins);
                 hipLaunchKernelGGL(k_descriptor, dim3(O.maxf, nf), dim3(128), 0, st, (const float4*)s->kp,
                                    (const float*)s->orient, (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap,
                                    (const int*)s->counts, s->desc);
@@ -1203,6 +1294,7 @@ int create_impl(mif_sift* s)
     MIF_HIP(hipMemset(s->counts, 0, B * CNT_WORDS * sizeof(int)));
     MIF_HIP(hipHostMalloc(&s->h_counts, B * CNT_WORDS * sizeof(int)));
     build_taps(s->taps, s->fr);
+    build_ori_bins(&s->ori_bins);
     for (int l = 0; l < kLevels; l++) {
         memset(&s->ktaps[l], 0, sizeof(Taps));
         if ((int)s->taps[l].size() > kMaxTaps) {
