@@ -15,6 +15,7 @@
 #include <cstdint>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include "mif_common.h"
 
 namespace {
@@ -100,8 +101,8 @@ __device__ __forceinline__ void top2_insert(Top2& t, float s, int i)
     }
 }
 
-// grid: (ceil(nq_cap / 128), nsplit, npairs). Wave v of block b owns query rows
-// [128 b + 32 v, +32); the block walks its share of the database in chunks of
+// Wave v of a block owns query rows [128 t + 32 v, +32) of query tile t; the
+// block walks one split of the database in chunks of
 // 64 rows (two 32-row MFMA tiles) staged in LDS and shared by the four waves.
 //
 // The queries are the B operand of the MFMA and live in registers for the whole
@@ -117,11 +118,17 @@ __device__ __forceinline__ void top2_insert(Top2& t, float s, int i)
 // MFMA over buffer (c & 1) | top-2 update. Staging loads are unconditional (row
 // and column indices are clamped into the matrix, invalid values are replaced
 // at the LDS store), so nothing between the loads and the MFMA loop waits.
+//
+// The grid is a fixed number of blocks that draw work items from a counter: an
+// item is (pair, split of the database, tile of 128 queries), enumerated from
+// the row counts in device memory, so pairs with few rows cost no idle blocks.
+// Every block leaves the loop at the first item index past the total.
 template <int KSTEPS, bool VEC>
-__global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int nq_cap, int nd_cap, int dim, int ld,
-                                                       const float* __restrict__ qn, const float* __restrict__ dn,
-                                                       int nsplit, float* __restrict__ part_s,
-                                                       int* __restrict__ part_i)
+__global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int npairs, int nq_cap, int nd_cap, int dim,
+                                                       int ld, const float* __restrict__ qn_all,
+                                                       const float* __restrict__ dn_all, int nsplit,
+                                                       float* __restrict__ part_s_all, int* __restrict__ part_i_all,
+                                                       unsigned int* __restrict__ work_counter)
 {
     constexpr int K = 2 * KSTEPS;
     constexpr int KP = KSTEPS + 4;
@@ -130,24 +137,58 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int nq_cap
     constexpr int RSTEP = 256 / K4;            // rows between a thread's consecutive float4
     __shared__ __attribute__((aligned(16))) float s_b[2][2 * kDC * KP];
     __shared__ __attribute__((aligned(16))) float s_dn[2][kDC];
-    const mif_match_pair& pr = tbl.p[blockIdx.z];
-    const float* __restrict__ Q = pr.d_q;
-    const float* __restrict__ D = pr.d_db;
-    const int* d_nq = pr.d_nq;
-    const int* d_nd = pr.d_nd;
-    qn += (size_t)blockIdx.z * nq_cap;
-    dn += (size_t)blockIdx.z * nd_cap;
-    part_s += (size_t)blockIdx.z * nsplit * nq_cap * 2;
-    part_i += (size_t)blockIdx.z * nsplit * nq_cap * 2;
-    const int nq = d_nq ? min(*d_nq, nq_cap) : nq_cap;
-    const int nd = d_nd ? min(*d_nd, nd_cap) : nd_cap;
+    __shared__ int s_first[kMaxPairs + 1];     // first item of every pair, then the total
+    __shared__ int s_item;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int half = lane >> 5;
     const int col = lane & 31;
-    const int qbase = blockIdx.x * (kQT * kWaves) + wave * kQT;
-    if (blockIdx.x * (kQT * kWaves) >= nq) return;          // uniform over the block
+
+    if (tid == 0) {
+        int total = 0;
+        for (int z = 0; z < npairs; z++) {
+            s_first[z] = total;
+            const mif_match_pair& pz = tbl.p[z];
+            const int nqz = pz.d_nq ? min(*pz.d_nq, nq_cap) : nq_cap;
+            const int ndz = pz.d_nd ? min(*pz.d_nd, nd_cap) : nd_cap;
+            const int chunks = (ndz + kDC - 1) / kDC;
+            const int per = (chunks + nsplit - 1) / nsplit;
+            const int live = per > 0 ? (chunks + per - 1) / per : 0;         // splits that hold rows
+            total += ((nqz + kQT * kWaves - 1) / (kQT * kWaves)) * live;
+        }
+        s_first[npairs] = total;
+    }
+
+    // staging coordinates of this thread: float4 column k4 of rows r0, r0 + RSTEP, ...
+    const int k4 = tid % K4;
+    const int r0 = tid / K4;
+    const bool m0 = 4 * k4 + 0 < dim, m1 = 4 * k4 + 1 < dim, m2 = 4 * k4 + 2 < dim, m3 = 4 * k4 + 3 < dim;
+    const int kc0 = min(4 * k4 + 0, dim - 1), kc1 = min(4 * k4 + 1, dim - 1);
+    const int kc2 = min(4 * k4 + 2, dim - 1), kc3 = min(4 * k4 + 3, dim - 1);
+    const int k4c = m0 ? 4 * k4 : 0;           // a 16-byte load must start inside the row
+
+  for (;;) {
+    __syncthreads();                           // s_first is complete; the previous item is done with LDS
+    if (tid == 0) s_item = (int)atomicAdd(work_counter, 1u);
+    __syncthreads();
+    const int item = s_item;
+    if (item >= s_first[npairs]) break;        // uniform over the block
+    int z = 0;
+    while (item >= s_first[z + 1]) z++;
+    const mif_match_pair& pr = tbl.p[z];
+    const float* __restrict__ Q = pr.d_q;
+    const float* __restrict__ D = pr.d_db;
+    const float* __restrict__ qn = qn_all + (size_t)z * nq_cap;
+    const float* __restrict__ dn = dn_all + (size_t)z * nd_cap;
+    float* __restrict__ part_s = part_s_all + (size_t)z * nsplit * nq_cap * 2;
+    int* __restrict__ part_i = part_i_all + (size_t)z * nsplit * nq_cap * 2;
+    const int nq = pr.d_nq ? min(*pr.d_nq, nq_cap) : nq_cap;
+    const int nd = pr.d_nd ? min(*pr.d_nd, nd_cap) : nd_cap;
+    const int qtiles = (nq + kQT * kWaves - 1) / (kQT * kWaves);
+    const int split = (item - s_first[z]) / qtiles;             // consecutive items share database rows
+    const int qtile = (item - s_first[z]) - split * qtiles;
+    const int qbase = qtile * (kQT * kWaves) + wave * kQT;
 
     // B fragments (queries): lane holds q[qbase + col][2 kk + half]
     float qf[KSTEPS];
@@ -174,16 +215,9 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int nq_cap
 
     const int chunks = (nd + kDC - 1) / kDC;
     const int per = (chunks + nsplit - 1) / nsplit;
-    const int c_lo = blockIdx.y * per;
+    const int c_lo = split * per;
     const int c_hi = min(chunks, c_lo + per);
 
-    // staging coordinates of this thread: float4 column k4 of rows r0, r0 + RSTEP, ...
-    const int k4 = tid % K4;
-    const int r0 = tid / K4;
-    const bool m0 = 4 * k4 + 0 < dim, m1 = 4 * k4 + 1 < dim, m2 = 4 * k4 + 2 < dim, m3 = 4 * k4 + 3 < dim;
-    const int kc0 = min(4 * k4 + 0, dim - 1), kc1 = min(4 * k4 + 1, dim - 1);
-    const int kc2 = min(4 * k4 + 2, dim - 1), kc3 = min(4 * k4 + 3, dim - 1);
-    const int k4c = m0 ? 4 * k4 : 0;           // a 16-byte load must start inside the row
 
     float4 stage[NV];
     float stage_dn = 0.0f;
@@ -276,7 +310,7 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int nq_cap
         consider(acc0, c * kDC, &s_dn[buf][0], full);
         consider(acc1, c * kDC + 32, &s_dn[buf][32], full);
     };
-    if (c_lo < c_hi) load_chunk(c_lo);
+    load_chunk(c_lo);                          // c_lo < c_hi for every enumerated item
     for (int c = c_lo; c < c_hi; c += 2) {
         chunk_step(c, 0);
         if (c + 1 < c_hi) chunk_step(c + 1, 1);
@@ -288,11 +322,12 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int nq_cap
         top2_insert(best, os1, oi1);
         top2_insert(best, os2, oi2);
         if (half == 0 && qi < nq) {
-            const size_t o = ((size_t)blockIdx.y * nq_cap + qi) * 2;
+            const size_t o = ((size_t)split * nq_cap + qi) * 2;
             part_s[o] = best.s1; part_s[o + 1] = best.s2;
             part_i[o] = best.i1; part_i[o + 1] = best.i2;
         }
     }
+  }
 }
 
 // grid (ceil(nq_cap/128), npairs). A thread owns a query: it merges the splits'
@@ -437,6 +472,8 @@ struct mif_matcher {
     int* d_idx = nullptr;
     float* d_dist = nullptr;
     float* d_score = nullptr;
+    unsigned int* work = nullptr;   // work-item counter of k_match_partial
+    int blocks = 512;               // persistent blocks: two per compute unit
 };
 
 namespace {
@@ -447,7 +484,7 @@ void free_matcher(mif_matcher* m)
 {
     (void)hipFree(m->qn); (void)hipFree(m->dn); (void)hipFree(m->part_s); (void)hipFree(m->part_i);
     (void)hipFree(m->d_q); (void)hipFree(m->d_db); (void)hipFree(m->d_idx); (void)hipFree(m->d_dist);
-    (void)hipFree(m->d_score);
+    (void)hipFree(m->d_score); (void)hipFree(m->work);
 }
 
 int pick_split(int nq, int nd, int npairs, bool device_counts)
@@ -455,6 +492,8 @@ int pick_split(int nq, int nd, int npairs, bool device_counts)
     // Enough blocks to load every CU several times over, but no split shorter than 4 chunks.
     // With device-side row counts nq / nd are capacities; the rows present are assumed to be
     // an eighth of them (blocks beyond the real counts exit at once).
+    if (const char* e = getenv("MIF_MATCH_SPLIT"))       // tuning override
+        return std::max(1, std::min(atoi(e), kMaxSplit));
     if (device_counts) {
         nq = std::max(1, nq / 8);
         nd = std::max(1, nd / 8);
@@ -519,11 +558,11 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
                 hipLaunchKernelGGL(k_row_norms<true>, dim3((nq + 255) / 256, np), dim3(256), 0, st, tbl, 0, nq, dim, ld, qn);
             else
                 hipLaunchKernelGGL(k_row_norms<false>, dim3((nq + 255) / 256, np), dim3(256), 0, st, tbl, 0, nq, dim, ld, qn);
-            dim3 grid((nq + kQT * kWaves - 1) / (kQT * kWaves), nsplit, np);
+            MIF_HIP(hipMemsetAsync(m->work, 0, sizeof(unsigned int), st));
             const bool vec = vec_db;
-#define MIF_LAUNCH_PARTIAL(KS, V)                                                                             \
-    hipLaunchKernelGGL((k_match_partial<KS, V>), grid, dim3(256), 0, st, tbl, nq, nd, dim, ld, (const float*)qn, \
-                       (const float*)dn, nsplit, ps, pi)
+#define MIF_LAUNCH_PARTIAL(KS, V)                                                                              \
+    hipLaunchKernelGGL((k_match_partial<KS, V>), dim3(m->blocks), dim3(256), 0, st, tbl, np, nq, nd, dim, ld,    \
+                       (const float*)qn, (const float*)dn, nsplit, ps, pi, m->work)
             if (dim <= 64) { if (vec) MIF_LAUNCH_PARTIAL(32, true); else MIF_LAUNCH_PARTIAL(32, false); }
             else           { if (vec) MIF_LAUNCH_PARTIAL(64, true); else MIF_LAUNCH_PARTIAL(64, false); }
 #undef MIF_LAUNCH_PARTIAL
@@ -569,6 +608,10 @@ int mif_match_create_batched(int device, int max_query, int max_database, int ma
     if ((e = hipMalloc(&m->dn, P * max_database * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->part_s, P * kMaxSplit * max_query * 2 * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->part_i, P * kMaxSplit * max_query * 2 * sizeof(int))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&m->work, sizeof(unsigned int))) != hipSuccess) return fail(e);
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+        m->blocks = 2 * cus;
     *out = m;
     return MIF_OK;
 }
