@@ -76,7 +76,8 @@ class MifError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libmi_features.so")
+    # MIF_LIBRARY selects another build of the same ABI (kernel experiments)
+    return os.environ.get("MIF_LIBRARY") or os.path.join(_HERE, "libmi_features.so")
 
 
 def load_library():
