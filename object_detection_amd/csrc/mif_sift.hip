@@ -613,73 +613,53 @@ __device__ __forceinline__ int octave_base(const int* counts, int o)
     return b;
 }
 
-// Emission pass: one wave per (frame, level, row). The row's accepted pixels
-// are dealt to the lanes (lane j takes the j-th set bit of the row's bitmask),
-// re-refined (the refinement is a pure function of the DoG stack) and written at
-// base(octave) + rowoff + j, i.e. in raster order.
+// Emission pass: one thread per keypoint slot p of (frame, octave). The thread
+// finds the row (level, y) whose range [rowoff, rowoff + rowcnt) holds p by
+// bisection over the exclusive scan, then the (p - rowoff)-th set bit of that
+// row's bitmask, re-refines the pixel (the refinement is a pure function of the
+// DoG stack) and writes the keypoint at base(octave) + p, i.e. in raster order.
 __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ dog, size_t dog_stride,
                                               const unsigned long long* __restrict__ mask,
                                               const int* __restrict__ rowcnt, const int* __restrict__ rowoff, int w,
                                               int h, int words, int o, int maxf, int cap,
                                               const int* __restrict__ counts, float4* __restrict__ kp)
 {
-    const int lane = threadIdx.x & 63;
-    const int rows = kIntervals * h;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int f = blockIdx.y;
-    if (r >= rows) return;
-    const size_t fr = (size_t)f * rows + r;
-    const int cnt = rowcnt[fr];
-    if (cnt == 0) return;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    counts += (size_t)f * CNT_WORDS;
+    if (p >= counts[CNT_OCT0 + o]) return;              // count is already cut at maxf
+    const int rows = kIntervals * h;
+    rowcnt += (size_t)f * rows;
+    rowoff += (size_t)f * rows;
+    // last row with rowoff <= p; rows without keypoints share their offset with the next
+    // row, so the last one among equals is the row that owns p
+    int lo = 0, hi = rows - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rowoff[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    const int r = lo;
+    int j = p - rowoff[r];                              // rank of the pixel within its row
+    const unsigned long long* mrow = mask + ((size_t)f * rows + r) * words;
+    int x = -1;
+    for (int k = 0; k < words; k++) {
+        unsigned long long m = mrow[k];
+        const int c = __popcll(m);
+        if (j < c) {
+            for (; j > 0; j--) m &= m - 1ull;           // drop the lower set bits
+            x = k * 64 + __ffsll((long long)m) - 1;
+            break;
+        }
+        j -= c;
+    }
+    if (x < 0) return;                                  // cannot happen: rowcnt counts the set bits
     const int s = r / h + 1;
     const int y = r - (s - 1) * h;
     const size_t items = (size_t)w * h;
     dog += (size_t)f * dog_stride;
-    counts += (size_t)f * CNT_WORDS;
-    kp += (size_t)f * cap;
-    const int base = octave_base(counts, o);
-    const int off = rowoff[fr];
-    const unsigned long long* mrow = mask + fr * words;
-    int seen = 0;                                       // set bits in the words before this group
-    for (int w0 = 0; w0 < words && seen < cnt; w0 += 64) {
-        const unsigned long long m = (w0 + lane < words) ? mrow[w0 + lane] : 0ull;
-        const int c = __popcll(m);
-        int incl = c;                                   // inclusive prefix of the popcounts
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int v = __shfl_up(incl, d);
-            if (lane >= d) incl += v;
-        }
-        const int group = __shfl(incl, 63);
-        for (int j0 = 0; j0 < group; j0 += 64) {
-            const int j = j0 + lane;                    // my set bit within this group of words
-            int myword = -1;
-            unsigned long long mym = 0ull;
-            int before = 0;
-            for (int k = 0; k < 64; k++) {
-                const int ik = __shfl(incl, k);
-                const int ck = __shfl(c, k);
-                const unsigned long long mk = __shfl(m, k);
-                if (myword < 0 && j < group && j >= ik - ck && j < ik) {
-                    myword = k;
-                    mym = mk;
-                    before = ik - ck;
-                }
-            }
-            if (myword >= 0) {
-                for (int t = j - before; t > 0; t--) mym &= mym - 1ull;   // drop the lower set bits
-                const int bit = __ffsll((long long)mym) - 1;
-                const int p = off + seen + j;
-                if (p < maxf) {
-                    float4 out;
-                    refine_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o,
-                                 (w0 + myword) * 64 + bit, y, &out);
-                    kp[base + p] = out;
-                }
-            }
-        }
-        seen += group;
-    }
+    float4 out;
+    refine_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o, x, y, &out);
+    kp[(size_t)f * cap + octave_base(counts, o) + p] = out;
 }
 
 // ------------------------------------------------------------------ gradients
@@ -1209,7 +1189,7 @@ int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc
         hipLaunchKernelGGL(k_scan_rows, dim3(nf), dim3(1024), 0, st, (const int*)O.rowcnt, O.rowoff, O.rows, O.maxf,
                            o, s->counts);
         if (O.maxf > 0) {
-            hipLaunchKernelGGL(k_emit, dim3((O.rows + 3) / 4, nf), dim3(256), 0, st, (const float*)O.dog, dog_stride,
+            hipLaunchKernelGGL(k_emit, dim3((O.maxf + 255) / 256, nf), dim3(256), 0, st, (const float*)O.dog, dog_stride,
                                (const unsigned long long*)O.mask, (const int*)O.rowcnt, (const int*)O.rowoff, O.w,
                                O.h, O.words, o, O.maxf, s->cap, (const int*)s->counts, s->kp);
             if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][3], st));
