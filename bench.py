@@ -38,43 +38,68 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="three handles instead of two: the extraction of batch k+1 overlaps the matching of "
+                         "batch k (higher throughput; per-kernel stage times then include the overlap)")
     return ap.parse_args()
 
 
-def make_frames(width, height, batch, rank):
+def _frame(job):
     from synth import blob_image
-    frames = [blob_image(width, height, seed=1234 + 100 * rank, channels=3, shift=(2 * t, t)) for t in range(batch)]
+    width, height, seed, t = job
+    return blob_image(width, height, seed=seed, channels=3, shift=(2 * t, t))
+
+
+def make_frames(width, height, batch, rank):
+    """Frame t = the seeded blob field translated by (2t, t). Rendered by a few worker processes
+    (numpy only; called before anything touches the GPU)."""
+    jobs = [(width, height, 1234 + 100 * rank, t) for t in range(batch)]
+    workers = min(8, batch)
+    if workers > 1:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(workers) as pool:
+            frames = pool.map(_frame, jobs)
+    else:
+        frames = [_frame(j) for j in jobs]
     return np.stack(frames)
 
 
 class Pipeline:
-    """Two batched SIFT handles used alternately (so the previous batch's last frame is still in
-    HBM when the next batch is matched against it) and one batched matcher per handle."""
+    """Batched SIFT handles used round-robin, each with its own stream and matcher. Batch k is
+    extracted on handle k % N and then matched (frame 0 against the last frame of batch k - 1,
+    which is still in HBM in the previous handle).
 
-    def __init__(self, oda, torch, dev_index, width, height, batch):
+    N = 2 (default): a handle waits for everything the other one has enqueued, so batches run
+    back to back and the per-stage times are those of the kernels alone.
+    N = 3 (--overlap): a handle is reused only after the matcher that read its results two
+    steps later has finished, so the extraction of batch k + 1 overlaps the matching of batch
+    k (the matcher is bound by the matrix cores, the extraction by memory and vector work)."""
+
+    def __init__(self, oda, torch, dev_index, width, height, batch, overlap=False):
+        self.N = 3 if overlap else 2
         self.oda, self.torch, self.B = oda, torch, batch
         self.dev = torch.device("cuda", dev_index)
-        self.h = [oda.SiftExtractor(width, height, 3, device=dev_index, batch=batch) for _ in range(2)]
+        self.h = [oda.SiftExtractor(width, height, 3, device=dev_index, batch=batch) for _ in range(self.N)]
         self.cap = self.h[0].capacity
-        self.m = [oda.Matcher(self.cap, self.cap, device=dev_index, max_pairs=batch) for _ in range(2)]
+        self.m = [oda.Matcher(self.cap, self.cap, device=dev_index, max_pairs=batch) for _ in range(self.N)]
         B, cap = batch, self.cap
-        self.idx = [torch.zeros((B, cap, 2), dtype=torch.int32, device=self.dev) for _ in range(2)]
-        self.dist = [torch.zeros((B, cap, 2), dtype=torch.float32, device=self.dev) for _ in range(2)]
-        self.good = [torch.zeros((B, cap), dtype=torch.uint8, device=self.dev) for _ in range(2)]
-        self.summ = [torch.zeros((B, 2), dtype=torch.int32, device=self.dev) for _ in range(2)]
+        self.idx = [torch.zeros((B, cap, 2), dtype=torch.int32, device=self.dev) for _ in range(self.N)]
+        self.dist = [torch.zeros((B, cap, 2), dtype=torch.float32, device=self.dev) for _ in range(self.N)]
+        self.good = [torch.zeros((B, cap), dtype=torch.uint8, device=self.dev) for _ in range(self.N)]
+        self.summ = [torch.zeros((B, 2), dtype=torch.int32, device=self.dev) for _ in range(self.N)]
         self.res = [h.device_results() for h in self.h]
-        self.pairs = [self._pairs(k) for k in range(2)]
+        self.pairs = [self._pairs(k) for k in range(self.N)]
         self.step_no = 0
 
     def _pairs(self, k):
         B, cap = self.B, self.cap
         _, _, des, cnt = self.res[k]
-        _, _, pdes, pcnt = self.res[1 - k]
+        _, _, pdes, pcnt = self.res[(k - 1) % self.N]
         out = []
         for b in range(B):
             if b == 0:
@@ -88,14 +113,19 @@ class Pipeline:
 
     def step(self, frames_ptr):
         from object_detection_amd import _lib
-        k = self.step_no & 1
-        h, other = self.h[k], self.h[1 - k]
-        # the other handle's stream holds the previous batch: its descriptors feed pair 0, and its
-        # matcher still reads this handle's old results
-        h.wait_for(other)
+        k = self.step_no % self.N
+        h = self.h[k]
+        # this handle's old results were the database of pair 0 of the matcher that ran N - 1 steps
+        # ago on the next handle's stream
+        h.wait_for(self.h[(k + 1) % self.N])
         h.enqueue(frames_ptr, self.B, True)
+        if self.N > 2:
+            h.wait_for(self.h[(k - 1) % self.N])        # pair 0 reads the previous batch's descriptors
         self.m[k].top2_batch_device(self.pairs[k], self.cap, self.cap, 127, 128, _lib.FILTER_SIFT, stream=h.stream())
         self.step_no += 1
+
+    def last(self):
+        return (self.step_no - 1) % self.N
 
     def sync(self):
         for h in self.h:
@@ -133,6 +163,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    frames_np = make_frames(args.width, args.height, args.batch, rank)      # before the GPU is initialised
     import torch
     import object_detection_amd as oda
     if not torch.cuda.is_available():
@@ -147,9 +178,8 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    frames_np = make_frames(args.width, args.height, args.batch, rank)
     frames = torch.from_numpy(frames_np).to(torch.device("cuda", local_rank))
-    pipe = Pipeline(oda, torch, local_rank, args.width, args.height, args.batch)
+    pipe = Pipeline(oda, torch, local_rank, args.width, args.height, args.batch, overlap=args.overlap)
 
     for _ in range(args.warmup):
         pipe.step(frames.data_ptr())
@@ -180,8 +210,8 @@ def main():
     alg_bytes = ALG_BYTES_PER_PX_OCTAVE * sum(px) * args.batch
     achieved = alg_bytes / (blur_ms * 1e-3) / 1e9
     launches = 18
-    summ = pipe.summ[(pipe.step_no - 1) & 1].cpu().numpy()
-    counts = pipe.h[(pipe.step_no - 1) & 1].read_counts(args.batch - 1)
+    summ = pipe.summ[pipe.last()].cpu().numpy()
+    counts = pipe.h[pipe.last()].read_counts(args.batch - 1)
 
     if rank == 0:
         frames_total = args.batch * args.steps * world
@@ -201,6 +231,7 @@ def main():
             "config": {"workload": "SIFT extract + match-vs-previous-frame on a synthetic %dx%d BGR sequence "
                                    "(stand-in for basketball.mp4, BASELINE.json configs[2])" % (args.width, args.height),
                        "frames_per_step": args.batch, "octaves": 3, "levels": 6,
+                       "pipeline": "3 handles, extraction overlaps matching" if args.overlap else "2 handles, batches back to back",
                        "keypoints_last_frame": counts[1], "good_matches_last_frame": int(summ[-1, 0]),
                        "parallelism": "frames sharded over %d GPU(s), no collective" % world},
             "roofline": {
