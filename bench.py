@@ -210,6 +210,16 @@ def main():
     alg_bytes = ALG_BYTES_PER_PX_OCTAVE * sum(px) * args.batch
     achieved = alg_bytes / (blur_ms * 1e-3) / 1e9
     launches = 18
+    # HBM-side bytes of the same launches from the PMC passes (FETCH_SIZE and WRITE_SIZE, separate
+    # rocprofv3 runs of this script, summarised by tools/pmc_traffic.py); they scale with the frame count
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_blur_traffic.json")) as fh:
+            pmc = json.load(fh)
+        if args.width == 1920 and args.height == 1080:
+            traffic = pmc["blur_bytes_per_frame"] * args.batch / launches
+    except (OSError, KeyError, ValueError):
+        pass
     summ = pipe.summ[pipe.last()].cpu().numpy()
     counts = pipe.h[pipe.last()].read_counts(args.batch - 1)
 
@@ -237,7 +247,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "k_blur_level (H+V+DoG fused, 18 launches per batch)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "avg_launch_us": blur_ms * 1e3 / launches,
                 "alg_bytes_per_launch": alg_bytes / launches,
                 "achieved_min_traffic": achieved * MIN_BYTES_PER_PX_OCTAVE / ALG_BYTES_PER_PX_OCTAVE,

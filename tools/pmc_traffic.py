@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Merges a FETCH_SIZE pass and a WRITE_SIZE pass of `rocprofv3 --pmc` over bench.py into per-launch
+memory-side bytes per kernel, and the scale-space (k_blur_level) total per frame.
+
+usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv frames_per_batch out.json
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 bytes by rocprofv3. The blur kernel reads
+with 4-byte-per-lane loads, for which FETCH_SIZE was checked against known byte counts (k_gray, k_detect)
+and needs no factor; its stores are 8 bytes per lane.
+"""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path, counter):
+    tot = collections.defaultdict(float)
+    calls = collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        tot[name] += float(r["Counter_Value"]) * 1024.0
+        calls[name].add(r["Dispatch_Id"])
+    return {k: (v, len(calls[k])) for k, v in tot.items()}
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    frames = int(sys.argv[3])
+    out = {"frames_per_batch": frames, "kernels": {}}
+    blur_bytes = blur_launches = 0.0
+    for k in sorted(set(fetch) | set(write)):
+        fb, fc = fetch.get(k, (0.0, 0))
+        wb, wc = write.get(k, (0.0, 0))
+        calls = max(fc, wc)
+        out["kernels"][k] = {"launches": calls, "fetch_bytes_per_launch": fb / max(fc, 1),
+                             "write_bytes_per_launch": wb / max(wc, 1)}
+        if k.startswith("k_blur_level"):
+            blur_bytes += fb / max(fc, 1) * calls + wb / max(wc, 1) * calls
+            blur_launches += calls
+    batches = blur_launches / 18.0                       # 18 blur launches per batch (3 octaves x 6 levels)
+    out["blur_bytes_per_frame"] = blur_bytes / batches / frames
+    out["blur_launches_per_batch"] = 18
+    json.dump(out, open(sys.argv[4], "w"), indent=1)
+    print("blur bytes per frame: %.1f MB over 18 launches" % (out["blur_bytes_per_frame"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()
