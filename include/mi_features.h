@@ -49,7 +49,9 @@ typedef struct mif_sift mif_sift;
 /* Replaces SIFT::init / sift_algorithm::sift_algorithm / sift_octave ctor
  * (SIFT/sift.cpp:2148-2189, 1731-1770, 1291-1538): builds the per-octave buffer
  * plan for a width x height image with `channels` = 1 (gray) or 3 (interleaved
- * BGR) on GPU `device`. up_scale must be 0. */
+ * BGR) on GPU `device`. up_scale != 0 builds the first octave at twice the input size by
+ * nearest-neighbour resampling (kResize_NN_*, SIFT/sift.cpp:134-210, 1140-1177, 1306-1310); keypoint
+ * coordinates are then in pixels of the resampled image, as in the reference. */
 int mif_sift_create(int device, int width, int height, int channels, int up_scale, mif_sift** out);
 /* Same, with room for `batch` frames per enqueue: every kernel launch then
  * covers the whole batch (frames are independent, as successive calls of the

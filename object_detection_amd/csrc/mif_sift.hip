@@ -32,6 +32,7 @@ constexpr int kInterpSteps = 5;    // _SIFT_MAX_INTERP_STEPS, sift.cpp:18
 constexpr int kOriBins = 36;       // _SIFT_ORI_HIST_BINS, sift.cpp:26
 constexpr int kOriLanes = 16;      // _SIFT_ORIENT_GPU_BLOCKSIZE, sift.cpp:27
 constexpr int kMaxTaps = 24;
+constexpr float kResampleRatio = 2.0f;   // _resample_ratio_x / _y, sift.cpp:812-813
 constexpr int kBlurTile = 64;      // output tile edge of the blur kernel
 
 // Kernel constants as the reference's kernels see them: the host prints them
@@ -105,6 +106,35 @@ __global__ void k_gray_bgr_x4(const uint8_t* __restrict__ in, float* __restrict_
     o.z = gray_of_bgr((float)((w1 >> 16) & 255u), (float)(w1 >> 24), (float)(w2 & 255u));
     o.w = gray_of_bgr((float)((w2 >> 8) & 255u), (float)((w2 >> 16) & 255u), (float)(w2 >> 24));
     reinterpret_cast<float4*>(out + (size_t)blockIdx.z * n)[i] = o;
+}
+
+// First octave at twice the input size (up_scale): kResize_NN_3ch_8b followed by
+// kColor_interleaved_ch, resp. the host conversion followed by kResize_NN_1ch_32b
+// (sift.cpp:134-210, 1140-1177), in one pass. (w, h) is the resampled size, (ws, hs)
+// the input's; pixels whose source falls outside are 0.
+template <int C>
+__global__ void k_base_upscaled(const uint8_t* __restrict__ in, float* __restrict__ out, int w, int h, int ws,
+                                int hs, float ratio)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    in += (size_t)blockIdx.z * ws * hs * C;
+    out += (size_t)blockIdx.z * w * h;
+    const float fy = ((float)y + 0.4995f) / ratio;
+    const float fx = ((float)x + 0.4995f) / ratio;
+    const int ps = (int)fy * ws + (int)fx;
+    const bool inside = fx < (float)ws && fy < (float)hs;
+    float v;
+    if (C == 3) {
+        const float b = inside ? (float)in[3 * ps] : 0.0f;
+        const float g = inside ? (float)in[3 * ps + 1] : 0.0f;
+        const float r = inside ? (float)in[3 * ps + 2] : 0.0f;
+        v = gray_of_bgr(b, g, r);
+    } else {
+        v = inside ? (float)in[ps] / 255.0f : 0.0f;
+    }
+    out[(size_t)y * w + x] = v;
 }
 
 // sift.cpp:113-132 kDown_pyramid with wo = 2w, d = 2, ss_img_id = 3
@@ -1090,6 +1120,7 @@ void build_ori_bins(OriBins* out)
 
 struct mif_sift {
     int device = 0, W = 0, H = 0, C = 1, cap = 0, batch = 1;
+    bool up = false;                       // first octave at twice the input size
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_dep = nullptr;
     OctaveBuf oct[kOctaves];
@@ -1155,7 +1186,17 @@ int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc
         const size_t pyr_stride = O.items * kLevels, dog_stride = O.items * (kLevels - 1);
         if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][0], st));
         if (o == 0) {
-            if (s->C == 3 && items % 4 == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 3u) == 0)
+            if (s->up) {
+                // source size as the reference derives it (sift.cpp:1144-1145)
+                const int ws = (int)((float)O.w / kResampleRatio), hs = (int)((float)O.h / kResampleRatio);
+                const dim3 g((O.w + 255) / 256, O.h, nf);
+                if (s->C == 3)
+                    hipLaunchKernelGGL(k_base_upscaled<3>, g, dim3(256), 0, st, (const uint8_t*)d_pixels, O.base, O.w,
+                                       O.h, ws, hs, kResampleRatio);
+                else
+                    hipLaunchKernelGGL(k_base_upscaled<1>, g, dim3(256), 0, st, (const uint8_t*)d_pixels, O.base, O.w,
+                                       O.h, ws, hs, kResampleRatio);
+            } else if (s->C == 3 && items % 4 == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 3u) == 0)
                 hipLaunchKernelGGL(k_gray_bgr_x4, dim3((items / 4 + 255) / 256, 1, nf), dim3(256), 0, st,
                                    (const uint8_t*)d_pixels, O.base, items);
             else if (s->C == 3)
@@ -1248,8 +1289,14 @@ int create_impl(mif_sift* s)
     for (int o = 0; o < kOctaves; o++) {
         OctaveBuf& O = s->oct[o];
         // sift.cpp:1313-1314: size_t = int / std::pow(2, id)
-        O.w = (int)(size_t)(s->W / std::pow(2, o));
-        O.h = (int)(size_t)(s->H / std::pow(2, o));
+        if (s->up) {
+            // sift.cpp:1306-1310: _resample_ratio (2.0f) * size_t / std::pow(2, id), truncated
+            O.w = (int)(size_t)(kResampleRatio * (size_t)s->W / std::pow(2, o));
+            O.h = (int)(size_t)(kResampleRatio * (size_t)s->H / std::pow(2, o));
+        } else {
+            O.w = (int)(size_t)(s->W / std::pow(2, o));
+            O.h = (int)(size_t)(s->H / std::pow(2, o));
+        }
         O.items = (size_t)O.w * O.h;
         O.maxf = (int)(O.items / 100);     // sift.cpp:1356
         O.words = (O.w + 63) / 64;
@@ -1307,18 +1354,17 @@ int mif_sift_create_batched(int device, int width, int height, int channels, int
         mif::set_error("mif_sift_create: bad geometry %dx%dx%d, batch %d", width, height, channels, batch);
         return MIF_ERR_INVALID_ARGUMENT;
     }
-    if ((long long)width * height * 3 >= (1ll << 31) || (long long)height * batch * 3 > 65535ll * 64) {
+    const long long zoom = up_scale ? 2 : 1;
+    if (zoom * width * zoom * height * 3 >= (1ll << 31) || zoom * height * batch * 3 > 65535ll * 64 ||
+        zoom * height > 65535) {
         mif::set_error("mif_sift_create: image or batch too large");
         return MIF_ERR_INVALID_ARGUMENT;
-    }
-    if (up_scale) {
-        mif::set_error("mif_sift_create: up_scale is not supported");
-        return MIF_ERR_UNSUPPORTED;
     }
     mif::DeviceGuard guard(device);
     if (!guard.ok) { mif::set_error("mif_sift_create: cannot select device %d", device); return MIF_ERR_HIP; }
     mif_sift* s = new mif_sift();
     s->device = device; s->W = width; s->H = height; s->C = channels; s->batch = batch;
+    s->up = up_scale != 0;
     const int rc = create_impl(s);
     if (rc != MIF_OK) { free_all(s); delete s; return rc; }
     *out = s;

@@ -46,6 +46,7 @@ constexpr int ORI_LANES = 16;
 constexpr double K_SIGMA = 1.6;
 constexpr double K_CONTR_THR_1 = 0.0108333;
 constexpr double K_CONTR_THR = 0.065;
+constexpr float K_RESAMPLE_RATIO = 2.0f;   // _resample_ratio_x / _y, sift.cpp:812-813
 constexpr double K_ORI_SIG_FCTR = 1.5;
 constexpr double K_ORI_RADIUS = 4.5;
 constexpr double K_ORI_PEAK_RATIO = 0.8;
@@ -71,6 +72,7 @@ struct Octave {
 
 struct Sift {
     int W = 0, H = 0, C = 1;
+    bool up = false;                     // first octave at twice the input size (sift.cpp:1306-1310)
     std::vector<float> taps[MAX_SCALES];
     int fr[MAX_SCALES];
     Octave oct[MAX_OCTAVES];
@@ -525,17 +527,27 @@ int orc_get_threads()
 }
 
 // sift.cpp:1291-1366 sift_octave ctor (sizes) and 1731-1770 sift_algorithm ctor
-void* orc_sift_create(int width, int height, int channels)
+void* orc_sift_create_up(int width, int height, int channels, int up_scale);
+
+void* orc_sift_create(int width, int height, int channels) { return orc_sift_create_up(width, height, channels, 0); }
+
+void* orc_sift_create_up(int width, int height, int channels, int up_scale)
 {
     if (width <= 0 || height <= 0 || (channels != 1 && channels != 3)) return nullptr;
     Sift* S = new Sift();
-    S->W = width; S->H = height; S->C = channels;
+    S->W = width; S->H = height; S->C = channels; S->up = up_scale != 0;
     build_taps(*S);
     for (int o = 0; o < MAX_OCTAVES; o++) {
         Octave& O = S->oct[o];
         O.id = o;
-        O.h = (int)(size_t)(height / std::pow(2, o));
-        O.w = (int)(size_t)(width / std::pow(2, o));
+        if (S->up) {
+            // sift.cpp:1306-1310: _resample_ratio (2.0f) * size_t / std::pow(2, id), truncated
+            O.h = (int)(size_t)(K_RESAMPLE_RATIO * (size_t)height / std::pow(2, o));
+            O.w = (int)(size_t)(K_RESAMPLE_RATIO * (size_t)width / std::pow(2, o));
+        } else {
+            O.h = (int)(size_t)(height / std::pow(2, o));
+            O.w = (int)(size_t)(width / std::pow(2, o));
+        }
         const size_t items = (size_t)O.w * O.h;
         O.max_feat = (uint32_t)(items / 100);
         O.pyr.assign(items * MAX_SCALES, 0.0f);
@@ -556,7 +568,33 @@ int orc_sift_run(void* hdl, const uint8_t* pixels, int want_descriptors)
     for (int o = 0; o < MAX_OCTAVES; o++) {
         Octave& O = S.oct[o];
         const int w = O.w, h = O.h;
-        if (o == 0) {
+        if (o == 0 && S.up) {
+            // sift.cpp:1140-1177: kResize_NN_3ch_8b then kColor_interleaved_ch, or
+            // copy_pixels_1ch8_to_1ch32 (into the non-resampled buffer, sift.cpp:907) then
+            // kResize_NN_1ch_32b (sift.cpp:134-210); source size as sift.cpp:1144-1145
+            float* dst = O.pyr.data();
+            const int ws = (int)((float)w / K_RESAMPLE_RATIO), hs = (int)((float)h / K_RESAMPLE_RATIO);
+            const float cb = (float)0.114, cg = (float)0.587, cr = (float)0.299;
+            const float val_scale = (float)0.0039215686;
+            for (int y = 0; y < h; y++) {
+                for (int x = 0; x < w; x++) {
+                    const float fy = ((float)y + 0.4995f) / K_RESAMPLE_RATIO;
+                    const float fx = ((float)x + 0.4995f) / K_RESAMPLE_RATIO;
+                    const int ps = (int)fy * ws + (int)fx;
+                    const bool inside = fx < (float)ws && fy < (float)hs;
+                    float v;
+                    if (S.C == 3) {
+                        const float b = inside ? (float)pixels[3 * ps] : 0.0f;
+                        const float g = inside ? (float)pixels[3 * ps + 1] : 0.0f;
+                        const float r = inside ? (float)pixels[3 * ps + 2] : 0.0f;
+                        v = (b * cb + g * cg + r * cr) * val_scale;
+                    } else {
+                        v = inside ? (float)pixels[ps] / 255.0f : 0.0f;
+                    }
+                    dst[y * w + x] = v;
+                }
+            }
+        } else if (o == 0) {
             float* dst = O.pyr.data();
             if (S.C == 3) {
                 // sift.cpp:55-72 kColor_interleaved_ch

@@ -18,6 +18,8 @@ def lib():
         L = C.CDLL(ORACLE_SO)
         L.orc_sift_create.restype = C.c_void_p
         L.orc_sift_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.orc_sift_create_up.restype = C.c_void_p
+        L.orc_sift_create_up.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_sift_destroy.argtypes = [C.c_void_p]
         L.orc_sift_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         for name in ("orc_sift_octave_width", "orc_sift_octave_height", "orc_sift_max_features",
@@ -93,9 +95,9 @@ def _arr(ptr, n, dtype=np.float32):
 class SiftOracle:
     """One CPU run of the restated reference pipeline, with every intermediate image exposed."""
 
-    def __init__(self, width, height, channels=1):
+    def __init__(self, width, height, channels=1, up_scale=False):
         self.L = lib()
-        self.h = self.L.orc_sift_create(width, height, channels)
+        self.h = self.L.orc_sift_create_up(width, height, channels, 1 if up_scale else 0)
         if not self.h:
             raise ValueError("bad image geometry")
         self.width, self.height, self.channels = width, height, channels

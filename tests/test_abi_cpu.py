@@ -33,8 +33,6 @@ def test_argument_errors_need_no_gpu():
     h = C.c_void_p()
     assert lib.mif_sift_create(0, 0, 10, 1, 0, C.byref(h)) == _lib.MIF_ERR_INVALID_ARGUMENT
     assert lib.mif_sift_create(0, 10, 10, 2, 0, C.byref(h)) == _lib.MIF_ERR_INVALID_ARGUMENT
-    assert lib.mif_sift_create(0, 10, 10, 1, 1, C.byref(h)) == _lib.MIF_ERR_UNSUPPORTED
-    assert b"up_scale" in lib.mif_last_error()
     assert lib.mif_match_create(0, 0, 5, C.byref(h)) == _lib.MIF_ERR_INVALID_ARGUMENT
 
 

@@ -192,3 +192,27 @@ def test_match_oracle_against_numpy():
     assert np.all(idx[:, 0] == 0) and np.all(idx[:, 1] == -1) and np.all(np.isinf(dist[:, 1]))
     idx, dist = orc.match_top2(q, db[:0])
     assert np.all(idx == -1) and np.all(np.isinf(dist))
+
+
+@pytest.mark.parametrize("channels", [1, 3])
+def test_up_scale_equals_pixel_replication(channels):
+    """up_scale resamples with ratio 2 by nearest neighbour (sift.cpp:134-210): every output pixel
+    (x, y) takes input pixel (x >> 1, y >> 1), so the run must equal a plain run on the image with
+    each pixel repeated 2 x 2."""
+    img = blob_image(128, 96, seed=21, channels=channels)
+    up = orc.SiftOracle(128, 96, channels, up_scale=True)
+    rep = orc.SiftOracle(256, 192, channels)
+    big = np.repeat(np.repeat(img, 2, axis=0), 2, axis=1)
+    assert up.run(img) == rep.run(big)
+    for o in range(3):
+        assert up.dims(o) == rep.dims(o) and up.count(o) == rep.count(o)
+        assert np.array_equal(up.pyramid(o).view(np.uint32), rep.pyramid(o).view(np.uint32))
+    fu, fr = up.all_features(), rep.all_features()
+    for a, b in zip(fu, fr):
+        assert np.array_equal(a, b)
+    assert up.count(0) > 0
+
+
+def test_up_scale_odd_size_geometry():
+    up = orc.SiftOracle(65, 47, 1, up_scale=True)
+    assert [up.dims(o) for o in range(3)] == [(130, 94), (65, 47), (32, 23)]

@@ -148,3 +148,27 @@ def test_full_hd_properties_and_parity():
     assert np.array_equal(f.keypoints.view(np.uint32), kp.view(np.uint32))
     assert np.array_equal(f.orientations.view(np.uint32), ori.view(np.uint32))
     assert np.array_equal(f.descriptors.view(np.uint32), des.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["box", "blob_bgr_200x150", "blob_bgr_97x61"])
+def test_up_scale_parity(name):
+    """First octave at twice the input size (kResize_NN_*, sift.cpp:134-210, 1140-1177)."""
+    img = load_case(name)
+    h, w = img.shape[:2]
+    c = 1 if img.ndim == 2 else 3
+    S = orc.SiftOracle(w, h, c, up_scale=True)
+    rc_o = S.run(img)
+    ex = oda.SiftExtractor(w, h, c, up_scale=True)
+    rc_g, f = ex.extract(img)
+    assert rc_g == rc_o
+    for o in range(3):
+        assert ex.octave_info(o) == (*S.dims(o), S.max_features(o))
+        p = S.pyramid(o)
+        for l in range(6):
+            assert np.array_equal(ex.level(o, l).view(np.uint32), p[l].view(np.uint32)), (o, l)
+    if rc_o == 0:
+        kp, octs, ori, des = S.all_features()
+        assert np.array_equal(f.keypoints.view(np.uint32), kp.view(np.uint32))
+        assert np.array_equal(f.orientations.view(np.uint32), ori.view(np.uint32))
+        assert np.array_equal(f.descriptors.view(np.uint32), des.view(np.uint32))
+        assert len(kp) > 0
