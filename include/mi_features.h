@@ -117,6 +117,12 @@ int mif_sift_copy_results(mif_sift* s, int frame, float* keypoints, float* orien
  * host. level 0..5 of the Gaussian pyramid, index 0..4 of the DoG stack. */
 int mif_sift_copy_level(mif_sift* s, int frame, int octave, int level, float* out);
 int mif_sift_copy_dog(mif_sift* s, int frame, int octave, int index, float* out);
+/* Replaces the _DEBUG probe SIFT::get_gray (SIFT/sift.h:23-26, sift.cpp:1590-1595, 1773-1801): the
+ * input of an octave's scale space before any blur, i.e. the gray conversion of the frame (resampled
+ * when up_scale is set) for octave 0 and the decimated level 3 of the previous octave otherwise. The
+ * reference hands out pyramid level 0, which its blur overwrites in place; here that input has its
+ * own buffer. */
+int mif_sift_copy_base(mif_sift* s, int frame, int octave, float* out);
 /* Gaussian taps of a level as the blur kernels use them (2*radius+1 floats;
  * Build_separable_filter_cof, SIFT/sift.cpp:819-889). Returns the radius. */
 int mif_sift_taps(const mif_sift* s, int level, float* out, int capacity);

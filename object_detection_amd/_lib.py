@@ -35,6 +35,7 @@ SYMBOLS = [
     ("mif_sift_read_counts", C.c_int, [_P, C.c_int, _PI, _PI]),
     ("mif_sift_copy_level", C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     ("mif_sift_copy_dog", C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
+    ("mif_sift_copy_base", C.c_int, [_P, C.c_int, C.c_int, _P]),
     ("mif_sift_taps", C.c_int, [_P, C.c_int, _PF, C.c_int]),
     ("mif_sift_set_timing", C.c_int, [_P, C.c_int]),
     ("mif_sift_stage_times", C.c_int, [_P, _P]),

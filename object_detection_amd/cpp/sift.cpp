@@ -91,7 +91,8 @@ namespace
         return MIF_OK;
     }
 
-    const float* probe(bool dog, float offload, const unsigned char* image, int width, int height, int depth, int oid,
+    // which: 0 = pyramid level sid, 1 = DoG image sid, 2 = input of the octave's scale space
+    const float* probe(int which, float offload, const unsigned char* image, int width, int height, int depth, int oid,
                        int sid)
     {
         std::vector<SIFT::sfeature> feats;
@@ -101,8 +102,9 @@ namespace
         int w = 0, h = 0;
         if (mif_sift_octave_info(G.handle, oid, &w, &h, nullptr) != MIF_OK) return nullptr;
         G.probe.assign((size_t)w * h, 0.0f);
-        const int rc = dog ? mif_sift_copy_dog(G.handle, 0, oid, sid, G.probe.data())
-                           : mif_sift_copy_level(G.handle, 0, oid, sid, G.probe.data());
+        const int rc = which == 1   ? mif_sift_copy_dog(G.handle, 0, oid, sid, G.probe.data())
+                       : which == 2 ? mif_sift_copy_base(G.handle, 0, oid, G.probe.data())
+                                    : mif_sift_copy_level(G.handle, 0, oid, sid, G.probe.data());
         return rc == MIF_OK ? G.probe.data() : nullptr;
     }
 }
@@ -147,13 +149,18 @@ namespace SIFT
     const float* get_blur(float offload, const unsigned char* image, int width, int height, int color_depth, int oid,
                           int sid)
     {
-        return probe(false, offload, image, width, height, color_depth, oid, sid);
+        return probe(0, offload, image, width, height, color_depth, oid, sid);
     }
 
     const float* get_diff_blur(float offload, const unsigned char* image, int width, int height, int color_depth,
                                int oid, int sid)
     {
-        return probe(true, offload, image, width, height, color_depth, oid, sid);
+        return probe(1, offload, image, width, height, color_depth, oid, sid);
+    }
+
+    const float* get_gray(float offload, const unsigned char* image, int width, int height, int color_depth, int oid)
+    {
+        return probe(2, offload, image, width, height, color_depth, oid, 0);
     }
 
     void set_device(int device)

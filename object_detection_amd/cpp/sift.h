@@ -59,6 +59,10 @@ namespace SIFT
     const float* get_diff_blur(float offload, const unsigned char* image, int width, int height, int color_depth,
                                int oid, int sid);
 
+    // Input of octave oid's scale space: the gray image (octave 0) or the decimated previous octave.
+    const float* get_gray(float offload, const unsigned char* image, int width, int height, int color_depth,
+                          int oid);
+
     // GPU used by the calls above (default 0); changing it drops the cached pipeline.
     void set_device(int device);
 }

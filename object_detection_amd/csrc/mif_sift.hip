@@ -1558,6 +1558,20 @@ int mif_sift_copy_dog(mif_sift* s, int frame, int octave, int index, float* out)
     return MIF_OK;
 }
 
+int mif_sift_copy_base(mif_sift* s, int frame, int octave, float* out)
+{
+    if (!s || !out || frame < 0 || frame >= s->batch || octave < 0 || octave >= kOctaves) {
+        mif::set_error("mif_sift_copy_base: bad argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(s->device);
+    const OctaveBuf& O = s->oct[octave];
+    MIF_HIP(hipStreamSynchronize(s->stream));
+    if (O.items)
+        MIF_HIP(hipMemcpy(out, O.base + (size_t)frame * O.items, O.items * sizeof(float), hipMemcpyDeviceToHost));
+    return MIF_OK;
+}
+
 int mif_sift_taps(const mif_sift* s, int level, float* out, int capacity)
 {
     if (!s || level < 0 || level >= kLevels) return MIF_ERR_INVALID_ARGUMENT;

@@ -138,6 +138,13 @@ class SiftExtractor:
         _lib.check(self._lib.mif_sift_copy_dog(self._h, frame, octave, index, out.ctypes.data))
         return out
 
+    def base(self, octave, frame=0):
+        """Input of the octave's scale space (gray conversion resp. decimated previous octave)."""
+        w, h, _ = self.octave_info(octave)
+        out = np.empty((h, w), np.float32)
+        _lib.check(self._lib.mif_sift_copy_base(self._h, frame, octave, out.ctypes.data))
+        return out
+
     def taps(self, level):
         buf = (C.c_float * 64)()
         fr = self._lib.mif_sift_taps(self._h, level, buf, 64)

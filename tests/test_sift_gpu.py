@@ -172,3 +172,21 @@ def test_up_scale_parity(name):
         assert np.array_equal(f.orientations.view(np.uint32), ori.view(np.uint32))
         assert np.array_equal(f.descriptors.view(np.uint32), des.view(np.uint32))
         assert len(kp) > 0
+
+
+def test_base_image_probe():
+    """mif_sift_copy_base (SIFT::get_gray): gray conversion, decimation and the up_scale resampling."""
+    g = load_case("blob_256x192")
+    ex = oda.SiftExtractor(256, 192, 1)
+    ex.extract(g, want_descriptors=False)
+    assert np.array_equal(ex.base(0), g.astype(np.float32) / np.float32(255.0))
+    assert np.array_equal(ex.base(1), ex.level(0, 3)[::2, ::2])          # kDown_pyramid, even sizes
+    bgr = load_case("blob_bgr_200x150").astype(np.float32)
+    ex3 = oda.SiftExtractor(200, 150, 3)
+    ex3.extract(bgr.astype(np.uint8), want_descriptors=False)
+    f = np.float32
+    want = ((bgr[..., 0] * f(0.114) + bgr[..., 1] * f(0.587)) + bgr[..., 2] * f(0.299)) * f(0.0039215686)
+    assert np.array_equal(ex3.base(0), want)
+    up = oda.SiftExtractor(200, 150, 3, up_scale=True)
+    up.extract(bgr.astype(np.uint8), want_descriptors=False)
+    assert np.array_equal(up.base(0), np.repeat(np.repeat(want, 2, axis=0), 2, axis=1))
