@@ -103,3 +103,26 @@ def test_ratio_filter_on_device():
     assert np.array_equal(good.cpu().numpy().astype(bool), keep)
     assert summ.cpu().numpy().tolist() == [int(keep.sum()), 300]
     assert keep.sum() >= 140
+
+
+def test_4k_gray_batch_parity():
+    """3840x2160 single-channel frames (the 4K configuration of the benchmark list) through the
+    batched device path: every frame of the batch equals the checker's run bit for bit."""
+    import torch
+    from synth import blob_image
+    frames = [blob_image(3840, 2160, seed=4321 + t, n_blobs=6000) for t in range(2)]
+    dev = torch.device("cuda:0")
+    px = torch.from_numpy(np.stack(frames)).to(dev)
+    ex = oda.SiftExtractor(3840, 2160, 1, batch=2)
+    assert [ex.octave_info(o)[:2] for o in range(3)] == [(3840, 2160), (1920, 1080), (960, 540)]
+    ex.enqueue(px.data_ptr(), 2)
+    S = orc.SiftOracle(3840, 2160)
+    for f, img in enumerate(frames):
+        rc_o = S.run(img)
+        rc_g, feat = ex.copy_results(f)
+        assert rc_g == rc_o == 0
+        kp, octs, ori, des = S.all_features()
+        assert feat.counts == [S.count(o) for o in range(3)] and sum(feat.counts) > 1000
+        assert np.array_equal(feat.keypoints.view(np.uint32), kp.view(np.uint32))
+        assert np.array_equal(feat.orientations.view(np.uint32), ori.view(np.uint32))
+        assert np.array_equal(feat.descriptors.view(np.uint32), des.view(np.uint32))
