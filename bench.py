@@ -223,6 +223,18 @@ def main():
     summ = pipe.summ[pipe.last()].cpu().numpy()
     counts = pipe.h[pipe.last()].read_counts(args.batch - 1)
 
+    # yardstick measured on this GPU: a 1 GiB device-to-device copy (bytes read + bytes written)
+    src_t = torch.empty(1 << 28, dtype=torch.float32, device=frames.device)
+    dst_t = torch.empty_like(src_t)
+    dst_t.copy_(src_t)
+    torch.cuda.synchronize()
+    tc = time.perf_counter()
+    for _ in range(5):
+        dst_t.copy_(src_t)
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * src_t.numel() * 4 / (time.perf_counter() - tc) / 1e9
+    del src_t, dst_t
+
     if rank == 0:
         frames_total = args.batch * args.steps * world
         out = {
@@ -251,6 +263,8 @@ def main():
                 "avg_launch_us": blur_ms * 1e3 / launches,
                 "alg_bytes_per_launch": alg_bytes / launches,
                 "achieved_min_traffic": achieved * MIN_BYTES_PER_PX_OCTAVE / ALG_BYTES_PER_PX_OCTAVE,
+                "achieved_traffic": (traffic / (blur_ms * 1e-3 / launches) / 1e9) if traffic else None,
+                "measured_copy_GBps": copy_gbs,
             },
             "stage_ms_per_batch": {"base": float(stage[:, 0].sum()), "scale_space": blur_ms,
                                    "detector": float(stage[:, 2].sum()), "orient_desc": float(stage[:, 3].sum())},
