@@ -168,11 +168,18 @@ def main():
     import object_detection_amd as oda
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # one rank per GPU; BENCH_BACKEND=gloo lets several ranks share a GPU for a rehearsal of this path
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     def barrier():
         if dist is not None:
@@ -197,7 +204,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    t = torch.tensor([dt], dtype=torch.float64, device=frames.device)
+    t = torch.tensor([dt], dtype=torch.float64, device=frames.device if backend == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
