@@ -28,8 +28,6 @@ constexpr int kDC = 64;      // database rows per staged chunk (two MFMA tiles)
 constexpr float kInf = __builtin_inff();
 constexpr int kMaxPairs = 32;   // pairs per launch (the table travels as a kernel argument)
 
-__device__ const float c_zero = 0.0f;
-
 struct PairTable {
     mif_match_pair p[kMaxPairs];
 };
@@ -138,6 +136,7 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int npairs
     __shared__ __attribute__((aligned(16))) float s_b[2][2 * kDC * KP];
     __shared__ __attribute__((aligned(16))) float s_dn[2][kDC];
     __shared__ int s_first[kMaxPairs + 1];     // first item of every pair, then the total
+    __shared__ int s_rows[kMaxPairs][2];       // query and database rows of every pair
     __shared__ int s_item;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -152,12 +151,15 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int npairs
             const mif_match_pair& pz = tbl.p[z];
             const int nqz = pz.d_nq ? min(*pz.d_nq, nq_cap) : nq_cap;
             const int ndz = pz.d_nd ? min(*pz.d_nd, nd_cap) : nd_cap;
+            s_rows[z][0] = nqz;
+            s_rows[z][1] = ndz;
             const int chunks = (ndz + kDC - 1) / kDC;
             const int per = (chunks + nsplit - 1) / nsplit;
             const int live = per > 0 ? (chunks + per - 1) / per : 0;         // splits that hold rows
             total += ((nqz + kQT * kWaves - 1) / (kQT * kWaves)) * live;
         }
         s_first[npairs] = total;
+        s_item = (int)atomicAdd(work_counter, 1u);
     }
 
     // staging coordinates of this thread: float4 column k4 of rows r0, r0 + RSTEP, ...
@@ -169,13 +171,17 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int npairs
     const int k4c = m0 ? 4 * k4 : 0;           // a 16-byte load must start inside the row
 
   for (;;) {
-    __syncthreads();                           // s_first is complete; the previous item is done with LDS
-    if (tid == 0) s_item = (int)atomicAdd(work_counter, 1u);
-    __syncthreads();
-    const int item = s_item;
+    __syncthreads();                           // s_item is set; the previous item is done with LDS
+    const int item = __builtin_amdgcn_readfirstlane(s_item);
+    __syncthreads();                           // every thread has read it
     if (item >= s_first[npairs]) break;        // uniform over the block
+    // the item after this one is drawn now and published when this one is finished, so the
+    // latency of the counter is covered by the work
+    int next_item = 0;
+    if (tid == 0) next_item = (int)atomicAdd(work_counter, 1u);
     int z = 0;
     while (item >= s_first[z + 1]) z++;
+    z = __builtin_amdgcn_readfirstlane(z);
     const mif_match_pair& pr = tbl.p[z];
     const float* __restrict__ Q = pr.d_q;
     const float* __restrict__ D = pr.d_db;
@@ -183,32 +189,16 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int npairs
     const float* __restrict__ dn = dn_all + (size_t)z * nd_cap;
     float* __restrict__ part_s = part_s_all + (size_t)z * nsplit * nq_cap * 2;
     int* __restrict__ part_i = part_i_all + (size_t)z * nsplit * nq_cap * 2;
-    const int nq = pr.d_nq ? min(*pr.d_nq, nq_cap) : nq_cap;
-    const int nd = pr.d_nd ? min(*pr.d_nd, nd_cap) : nd_cap;
+    const int nq = __builtin_amdgcn_readfirstlane(s_rows[z][0]);
+    const int nd = __builtin_amdgcn_readfirstlane(s_rows[z][1]);
     const int qtiles = (nq + kQT * kWaves - 1) / (kQT * kWaves);
     const int split = (item - s_first[z]) / qtiles;             // consecutive items share database rows
     const int qtile = (item - s_first[z]) - split * qtiles;
     const int qbase = qtile * (kQT * kWaves) + wave * kQT;
 
-    // B fragments (queries): lane holds q[qbase + col][2 kk + half]
-    float qf[KSTEPS];
+    float qf[KSTEPS];                          // B fragments, filled below
     const int qi = qbase + col;
-    {
-        // elements outside the matrix are read from a zero word instead, so that every load is
-        // unconditional and all of them are in flight together
-        const float* qr = Q + (size_t)min(qi, nq_cap - 1) * ld;
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; kk++) {
-            const int k = 2 * kk + half;
-            const float* p = (qi < nq && k < dim) ? qr + k : &c_zero;
-            qf[kk] = *p;
-        }
-    }
-    // A 32x32 result tile has the database row on the register index and the
-    // query on the lane: C[(reg&3) + 8 (reg>>2) + 4 half][col]. A lane therefore
-    // keeps ONE running top-2 for its query; lanes l and l + 32 hold the same
-    // query and are merged at the end.
-    const float qnv = (qi < nq) ? qn[qi] : 0.0f;
+    float qnv = 0.0f;
     Top2 best;
     best.s1 = best.s2 = kInf;
     best.i1 = best.i2 = 0x7fffffff;
@@ -310,7 +300,49 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int npairs
         consider(acc0, c * kDC, &s_dn[buf][0], full);
         consider(acc1, c * kDC + 32, &s_dn[buf][32], full);
     };
-    load_chunk(c_lo);                          // c_lo < c_hi for every enumerated item
+    load_chunk(c_lo);                          // c_lo < c_hi for every enumerated item; in flight
+                                               // while the queries are fetched
+    // B fragments (queries): lane holds q[qbase + col][2 kk + half]
+    {
+        // every load is unconditional (row and column clamped into the matrix) and all of them
+        // are in flight together; values outside the matrix are replaced afterwards
+        const float* qr = Q + (size_t)min(qi, nq - 1) * ld;
+        const bool row_ok = qi < nq;
+        if (VEC) {
+            // 16 bytes hold k = 4j .. 4j+3: this lane keeps the two of its half
+            // (in two rounds, so that the raw rows do not crowd the register file)
+            constexpr int HALF = K / 8;
+#pragma unroll
+            for (int h0 = 0; h0 < K / 4; h0 += HALF) {
+                float rx[HALF], ry[HALF], rz[HALF], rw[HALF];
+#pragma unroll
+                for (int j = 0; j < HALF; j++) {
+                    const float4 v = *reinterpret_cast<const float4*>(qr + min(4 * (h0 + j), (dim - 1) & ~3));
+                    rx[j] = v.x; ry[j] = v.y; rz[j] = v.z; rw[j] = v.w;
+                }
+                asm volatile("" ::: "memory");  // keeps the loads above from sinking into the selects
+#pragma unroll
+                for (int j = 0; j < HALF; j++) {
+                    const int k0 = 4 * (h0 + j);
+                    const float e0 = half ? ry[j] : rx[j], e1 = half ? rw[j] : rz[j];
+                    qf[2 * (h0 + j) + 0] = (row_ok && k0 + 0 + half < dim) ? e0 : 0.0f;
+                    qf[2 * (h0 + j) + 1] = (row_ok && k0 + 2 + half < dim) ? e1 : 0.0f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; kk++) qf[kk] = qr[min(2 * kk + half, dim - 1)];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; kk++) qf[kk] = (row_ok && 2 * kk + half < dim) ? qf[kk] : 0.0f;
+        }
+    }
+    // A 32x32 result tile has the database row on the register index and the
+    // query on the lane: C[(reg&3) + 8 (reg>>2) + 4 half][col]. A lane therefore
+    // keeps ONE running top-2 for its query; lanes l and l + 32 hold the same
+    // query and are merged at the end.
+    qnv = (qi < nq) ? qn[qi] : 0.0f;
+
     for (int c = c_lo; c < c_hi; c += 2) {
         chunk_step(c, 0);
         if (c + 1 < c_hi) chunk_step(c + 1, 1);
@@ -327,6 +359,7 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int npairs
             part_i[o] = best.i1; part_i[o + 1] = best.i2;
         }
     }
+    if (tid == 0) s_item = next_item;
   }
 }
 
@@ -561,7 +594,7 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
             else
                 hipLaunchKernelGGL(k_row_norms<false>, dim3((nq + 255) / 256, np), dim3(256), 0, st, tbl, 0, nq, dim, ld, qn);
             MIF_HIP(hipMemsetAsync(m->work, 0, sizeof(unsigned int), st));
-            const bool vec = vec_db;
+            const bool vec = vec_db && vec_q;
 #define MIF_LAUNCH_PARTIAL(KS, V)                                                                              \
     hipLaunchKernelGGL((k_match_partial<KS, V>), dim3(m->blocks), dim3(256), 0, st, tbl, np, nq, nd, dim, ld,    \
                        (const float*)qn, (const float*)dn, nsplit, ps, pi, m->work)
