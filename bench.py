@@ -43,9 +43,8 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", action="store_true",
-                    help="three handles instead of two: the extraction of batch k+1 overlaps the matching of "
-                         "batch k (higher throughput; per-kernel stage times then include the overlap)")
+    ap.add_argument("--serial", action="store_true",
+                    help="run the matcher of a batch after its feature phase instead of beside the next one's")
     return ap.parse_args()
 
 
@@ -70,66 +69,101 @@ def make_frames(width, height, batch, rank):
 
 
 class Pipeline:
-    """Batched SIFT handles used round-robin, each with its own stream and matcher. Batch k is
-    extracted on handle k % N and then matched (frame 0 against the last frame of batch k - 1,
-    which is still in HBM in the previous handle).
+    """Two batched SIFT handles used alternately (own stream each), one matcher on a stream of its own.
 
-    N = 2 (default): a handle waits for everything the other one has enqueued, so batches run
-    back to back and the per-stage times are those of the kernels alone.
-    N = 3 (--overlap): a handle is reused only after the matcher that read its results two
-    steps later has finished, so the extraction of batch k + 1 overlaps the matching of batch
-    k (the matcher is bound by the matrix cores, the extraction by memory and vector work)."""
+    A step extracts batch k and matches batch k - 1 (every frame against the previous frame; frame 0
+    against the last frame of batch k - 2, whose descriptors were copied aside when that batch
+    finished). Order on the GPU:
 
-    def __init__(self, oda, torch, dev_index, width, height, batch, overlap=False):
-        self.N = 3 if overlap else 2
-        self.oda, self.torch, self.B = oda, torch, batch
+        pyramid(k)  ->  features(k)  ||  matcher(k - 1)   ->  pyramid(k + 1)  -> ...
+
+    The scale-space phase (bandwidth kernels) runs alone; the feature phase (vector and latency
+    bound) shares the GPU with the matcher (matrix cores). With serial=True the matcher of batch k
+    runs after features(k) instead and nothing overlaps."""
+
+    def __init__(self, oda, torch, dev_index, width, height, batch, serial=False):
+        from object_detection_amd import _lib
+        self._lib, self.lib = _lib, oda.load_library()
+        self.serial = serial
+        self.oda, self.torch, self.B, self.dev_index = oda, torch, batch, dev_index
         self.dev = torch.device("cuda", dev_index)
-        self.h = [oda.SiftExtractor(width, height, 3, device=dev_index, batch=batch) for _ in range(self.N)]
+        self.h = [oda.SiftExtractor(width, height, 3, device=dev_index, batch=batch) for _ in range(2)]
         self.cap = self.h[0].capacity
-        self.m = [oda.Matcher(self.cap, self.cap, device=dev_index, max_pairs=batch) for _ in range(self.N)]
+        self.m = oda.Matcher(self.cap, self.cap, device=dev_index, max_pairs=batch)
+        self.mstream = torch.cuda.Stream(device=self.dev)
         B, cap = batch, self.cap
-        self.idx = [torch.zeros((B, cap, 2), dtype=torch.int32, device=self.dev) for _ in range(self.N)]
-        self.dist = [torch.zeros((B, cap, 2), dtype=torch.float32, device=self.dev) for _ in range(self.N)]
-        self.good = [torch.zeros((B, cap), dtype=torch.uint8, device=self.dev) for _ in range(self.N)]
-        self.summ = [torch.zeros((B, 2), dtype=torch.int32, device=self.dev) for _ in range(self.N)]
+        # results of the matcher per handle parity
+        self.idx = [torch.zeros((B, cap, 2), dtype=torch.int32, device=self.dev) for _ in range(2)]
+        self.dist = [torch.zeros((B, cap, 2), dtype=torch.float32, device=self.dev) for _ in range(2)]
+        self.good = [torch.zeros((B, cap), dtype=torch.uint8, device=self.dev) for _ in range(2)]
+        self.summ = [torch.zeros((B, 2), dtype=torch.int32, device=self.dev) for _ in range(2)]
+        # descriptors and count of the last frame of a finished batch (three in rotation: one is
+        # being written while the matcher may still read the one from two batches ago)
+        self.snap_des = [torch.zeros((cap, 128), dtype=torch.float32, device=self.dev) for _ in range(3)]
+        self.snap_cnt = [torch.zeros((1,), dtype=torch.int32, device=self.dev) for _ in range(3)]
         self.res = [h.device_results() for h in self.h]
-        self.pairs = [self._pairs(k) for k in range(self.N)]
+        self._tables = {}
         self.step_no = 0
+        self.pending = False
 
     def _pairs(self, k):
-        B, cap = self.B, self.cap
-        _, _, des, cnt = self.res[k]
-        _, _, pdes, pcnt = self.res[(k - 1) % self.N]
-        out = []
-        for b in range(B):
-            if b == 0:
-                db, nd = pdes + (B - 1) * cap * 512, pcnt + (B - 1) * 32 + 12
-            else:
-                db, nd = des + (b - 1) * cap * 512, cnt + (b - 1) * 32 + 12
-            out.append(dict(q=des + b * cap * 512, db=db, nq=cnt + b * 32 + 12, nd=nd,
-                            idx2=self.idx[k][b].data_ptr(), dist2=self.dist[k][b].data_ptr(),
-                            good=self.good[k][b].data_ptr(), summary=self.summ[k][b].data_ptr()))
-        return out
+        """Pair table of batch k: queries in handle k % 2, database of frame 0 in snapshot (k - 1) % 3."""
+        key = (k % 2, (k - 1) % 3)
+        if key not in self._tables:
+            B, cap = self.B, self.cap
+            _, _, des, cnt = self.res[k % 2]
+            out = []
+            for b in range(B):
+                if b == 0:
+                    db, nd = self.snap_des[(k - 1) % 3].data_ptr(), self.snap_cnt[(k - 1) % 3].data_ptr()
+                else:
+                    db, nd = des + (b - 1) * cap * 512, cnt + (b - 1) * 32 + 12
+                out.append(dict(q=des + b * cap * 512, db=db, nq=cnt + b * 32 + 12, nd=nd,
+                                idx2=self.idx[k % 2][b].data_ptr(), dist2=self.dist[k % 2][b].data_ptr(),
+                                good=self.good[k % 2][b].data_ptr(), summary=self.summ[k % 2][b].data_ptr()))
+            self._tables[key] = out
+        return self._tables[key]
+
+    def _wait(self, waiter, signaller):
+        self._lib.check(self.lib.mif_stream_wait_stream(self.dev_index, ctypes.c_void_p(waiter),
+                                                        ctypes.c_void_p(signaller)))
+
+    def _match(self, k):
+        self.m.top2_batch_device(self._pairs(k), self.cap, self.cap, 127, 128, self._lib.FILTER_SIFT,
+                                 stream=self.mstream.cuda_stream)
 
     def step(self, frames_ptr):
-        from object_detection_amd import _lib
-        k = self.step_no % self.N
-        h = self.h[k]
-        # this handle's old results were the database of pair 0 of the matcher that ran N - 1 steps
-        # ago on the next handle's stream
-        h.wait_for(self.h[(k + 1) % self.N])
-        h.enqueue(frames_ptr, self.B, True)
-        if self.N > 2:
-            h.wait_for(self.h[(k - 1) % self.N])        # pair 0 reads the previous batch's descriptors
-        self.m[k].top2_batch_device(self.pairs[k], self.cap, self.cap, 127, 128, _lib.FILTER_SIFT, stream=h.stream())
+        k = self.step_no
+        h, other, ms = self.h[k % 2], self.h[(k - 1) % 2], self.mstream.cuda_stream
+        self._wait(h.stream(), other.stream())     # extraction runs batch after batch
+        self._wait(h.stream(), ms)                 # the matcher two batches back read this handle's results
+        h.enqueue_pyramid(frames_ptr, self.B)
+        if self.pending and not self.serial:
+            self._wait(ms, h.stream())             # beside the feature phase, not the scale spaces
+            self._match(k - 1)
+        h.enqueue_features(True)
+        h.snapshot_frame(self.B - 1, self.snap_des[k % 3].data_ptr(), self.snap_cnt[k % 3].data_ptr())
+        self.pending = True
         self.step_no += 1
+        if self.serial:
+            self.flush()
+
+    def flush(self):
+        """Matches the batch extracted last, if that has not happened yet."""
+        if self.pending:
+            k = self.step_no - 1
+            self._wait(self.mstream.cuda_stream, self.h[k % 2].stream())
+            self._match(k)
+            self.pending = False
 
     def last(self):
-        return (self.step_no - 1) % self.N
+        return (self.step_no - 1) % 2
 
     def sync(self):
+        self.flush()
         for h in self.h:
             h.sync()
+        self.mstream.synchronize()
 
 
 def cpu_baseline(frames, budget_s):
@@ -186,7 +220,7 @@ def main():
             dist.barrier()
 
     frames = torch.from_numpy(frames_np).to(torch.device("cuda", local_rank))
-    pipe = Pipeline(oda, torch, local_rank, args.width, args.height, args.batch, overlap=args.overlap)
+    pipe = Pipeline(oda, torch, local_rank, args.width, args.height, args.batch, serial=args.serial)
 
     for _ in range(args.warmup):
         pipe.step(frames.data_ptr())
@@ -260,7 +294,8 @@ def main():
             "config": {"workload": "SIFT extract + match-vs-previous-frame on a synthetic %dx%d BGR sequence "
                                    "(stand-in for basketball.mp4, BASELINE.json configs[2])" % (args.width, args.height),
                        "frames_per_step": args.batch, "octaves": 3, "levels": 6,
-                       "pipeline": "3 handles, extraction overlaps matching" if args.overlap else "2 handles, batches back to back",
+                       "pipeline": "matcher after each batch" if args.serial else
+                                   "matcher of batch k-1 beside the feature phase of batch k",
                        "keypoints_last_frame": counts[1], "good_matches_last_frame": int(summ[-1, 0]),
                        "parallelism": "frames sharded over %d GPU(s), no collective" % world},
             "roofline": {

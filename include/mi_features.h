@@ -86,6 +86,24 @@ int mif_sift_extract(mif_sift* s, const uint8_t* pixels, float* keypoints, float
  * nothing is copied back. want_descriptors = 0 stops after the detector (first
  * overload of sift.h). */
 int mif_sift_enqueue(mif_sift* s, const void* d_pixels, int nframes, int want_descriptors);
+/* The two phases of mif_sift_enqueue as separate calls, for callers that schedule other work of
+ * their own between or beside them: _pyramid builds the base images and scale spaces (+ DoG) of all
+ * octaves (the reference's kColor / kDown / kBlurH / kBlurV / kDiff launches, SIFT/sift.cpp:1140-1230,
+ * bandwidth kernels), _features runs detection, orientations and descriptors on them (kDetector,
+ * kOrientation, kDescriptor, kNormalize, sift.cpp:1232-1282). mif_sift_enqueue is _pyramid followed
+ * by _features. */
+int mif_sift_enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes);
+int mif_sift_enqueue_features(mif_sift* s, int want_descriptors);
+/* Copies the descriptor rows ([capacity][128] floats) and the keypoint count of one frame of the
+ * last batch into caller-owned device memory, in stream order on the handle's stream: the frame a
+ * video caller matches the next batch's first frame against (SIFT/main.cpp:103-153 keeps the
+ * previous frame's features on the host). */
+int mif_sift_snapshot_frame(mif_sift* s, int frame, float* d_descriptors, int32_t* d_count);
+/* Orders two streams of the caller's: everything enqueued on `waiter` after this call runs after
+ * everything enqueued on `signaller` before it. No counterpart in the reference, whose driver
+ * chains tasks with add_dependence (clDriver.h); streams are HIP stream handles (mif_sift_stream). */
+int mif_stream_wait_stream(int device, void* waiter, void* signaller);
+
 /* Blocks until everything enqueued on the handle has finished. */
 int mif_sift_sync(mif_sift* s);
 /* Makes everything enqueued on s from now on wait for what has been enqueued

@@ -647,6 +647,10 @@ int mif_match_create_batched(int device, int max_query, int max_database, int ma
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
         m->blocks = 2 * cus;
+    if (const char* e = getenv("MIF_MATCH_BLOCKS")) {        // tuning override: persistent blocks in total
+        const int n = atoi(e);
+        if (n >= 1 && n <= 65535) m->blocks = n;
+    }
     *out = m;
     return MIF_OK;
 }

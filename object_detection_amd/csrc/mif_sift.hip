@@ -1137,7 +1137,9 @@ struct mif_sift {
     bool frame_done = false;
     // optional per-stage timing: events at the stage boundaries of every octave
     bool timing = false, timed_frame = false, timed_desc = false;
-    hipEvent_t ev_stage[kOctaves][MIF_SIFT_STAGES + 1] = {};
+    hipEvent_t ev_stage[kOctaves][3] = {};   // pyramid phase: before base, before blur, after blur
+    hipEvent_t ev_feat[kOctaves][3] = {};    // feature phase: before detection, after emission, at the end
+    int pyramid_frames = 0;                  // frames whose scale spaces await the feature phase
 };
 
 namespace {
@@ -1171,7 +1173,9 @@ int launch_blur(int fr, const float* src, size_t src_stride, float* dst, float* 
     return MIF_OK;
 }
 
-int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc)
+// Phase 1 of a batch: base images and scale spaces (+ DoG) of all octaves. Only bandwidth
+// kernels; the octaves depend on each other through the decimation.
+int enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes)
 {
     hipStream_t st = s->stream;
     const int nf = nframes;
@@ -1179,6 +1183,7 @@ int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc
     MIF_HIP(hipMemsetAsync(s->counts, 0, (size_t)nf * CNT_WORDS * sizeof(int), st));
     const bool tm = s->timing;
     s->timed_frame = false;
+    s->pyramid_frames = 0;
     for (int o = 0; o < kOctaves; o++) {
         OctaveBuf& O = s->oct[o];
         const int items = (int)O.items;
@@ -1222,6 +1227,24 @@ int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc
             if (rc != MIF_OK) return rc;
         }
         if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][2], st));
+    }
+    MIF_HIP(hipGetLastError());
+    s->pyramid_frames = nf;
+    return MIF_OK;
+}
+
+// Phase 2: detection, emission, gradients, orientations and descriptors of all octaves
+// from the scale spaces phase 1 left in the handle.
+int enqueue_features(mif_sift* s, int want_desc)
+{
+    hipStream_t st = s->stream;
+    const int nf = s->pyramid_frames;
+    const bool tm = s->timing;
+    for (int o = 0; o < kOctaves; o++) {
+        OctaveBuf& O = s->oct[o];
+        if (O.items == 0) continue;
+        const size_t pyr_stride = O.items * kLevels, dog_stride = O.items * (kLevels - 1);
+        if (tm) MIF_HIP(hipEventRecord(s->ev_feat[o][0], st));
         MIF_HIP(hipMemsetAsync(O.rowcnt, 0, (size_t)nf * O.rows * sizeof(int), st));
         MIF_HIP(hipMemsetAsync(O.mask, 0, (size_t)nf * O.rows * O.words * sizeof(unsigned long long), st));
         hipLaunchKernelGGL(k_detect, dim3((O.w + 4 * kDetCols - 1) / (4 * kDetCols), (O.h + kDetRows - 1) / kDetRows, nf),
@@ -1233,7 +1256,7 @@ int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc
             hipLaunchKernelGGL(k_emit, dim3((O.maxf + 255) / 256, nf), dim3(256), 0, st, (const float*)O.dog, dog_stride,
                                (const unsigned long long*)O.mask, (const int*)O.rowcnt, (const int*)O.rowoff, O.w,
                                O.h, O.words, o, O.maxf, s->cap, (const int*)s->counts, s->kp);
-            if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][3], st));
+            if (tm) MIF_HIP(hipEventRecord(s->ev_feat[o][1], st));
             if (want_desc) {
                 const size_t grad_stride = O.items * kIntervals;
                 hipLaunchKernelGGL(k_gradient, dim3((O.w + 255) / 256, (O.h + kGradRows - 1) / kGradRows, kIntervals * nf),
@@ -1247,16 +1270,23 @@ int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc
                                    (const int*)s->counts, s->desc);
             }
         } else if (tm) {
-            MIF_HIP(hipEventRecord(s->ev_stage[o][3], st));
+            MIF_HIP(hipEventRecord(s->ev_feat[o][1], st));
         }
-        if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][4], st));
+        if (tm) MIF_HIP(hipEventRecord(s->ev_feat[o][2], st));
     }
     if (tm) { s->timed_frame = true; s->timed_desc = want_desc != 0; }
     hipLaunchKernelGGL(k_finish, dim3((nf + 63) / 64), dim3(64), 0, st, s->counts, nf, want_desc);
     MIF_HIP(hipGetLastError());
     MIF_HIP(hipEventRecord(s->ev1, st));
     s->frame_done = true;
+    s->pyramid_frames = 0;
     return MIF_OK;
+}
+
+int enqueue_frames(mif_sift* s, const void* d_pixels, int nframes, int want_desc)
+{
+    const int rc = enqueue_pyramid(s, d_pixels, nframes);
+    return rc != MIF_OK ? rc : enqueue_features(s, want_desc);
 }
 
 void free_all(mif_sift* s)
@@ -1273,8 +1303,10 @@ void free_all(mif_sift* s)
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->ev_dep) (void)hipEventDestroy(s->ev_dep);
     for (int o = 0; o < kOctaves; o++)
-        for (int i = 0; i <= MIF_SIFT_STAGES; i++)
+        for (int i = 0; i < 3; i++) {
             if (s->ev_stage[o][i]) (void)hipEventDestroy(s->ev_stage[o][i]);
+            if (s->ev_feat[o][i]) (void)hipEventDestroy(s->ev_feat[o][i]);
+        }
     if (s->stream) (void)hipStreamDestroy(s->stream);
 }
 
@@ -1407,6 +1439,55 @@ int mif_sift_enqueue(mif_sift* s, const void* d_pixels, int nframes, int want_de
     }
     mif::DeviceGuard guard(s->device);
     return enqueue_frames(s, d_pixels, nframes, want_descriptors);
+}
+
+int mif_sift_enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes)
+{
+    if (!s || !d_pixels) { mif::set_error("mif_sift_enqueue_pyramid: NULL argument"); return MIF_ERR_INVALID_ARGUMENT; }
+    if (nframes < 1 || nframes > s->batch) {
+        mif::set_error("mif_sift_enqueue_pyramid: %d frames do not fit the handle's batch of %d", nframes, s->batch);
+        return MIF_ERR_CAPACITY;
+    }
+    mif::DeviceGuard guard(s->device);
+    return enqueue_pyramid(s, d_pixels, nframes);
+}
+
+int mif_sift_enqueue_features(mif_sift* s, int want_descriptors)
+{
+    if (!s) return MIF_ERR_INVALID_ARGUMENT;
+    if (s->pyramid_frames < 1) {
+        mif::set_error("mif_sift_enqueue_features: no scale space is pending (call mif_sift_enqueue_pyramid first)");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(s->device);
+    return enqueue_features(s, want_descriptors);
+}
+
+int mif_sift_snapshot_frame(mif_sift* s, int frame, float* d_descriptors, int32_t* d_count)
+{
+    if (!s || !d_descriptors || !d_count || frame < 0 || frame >= s->batch) {
+        mif::set_error("mif_sift_snapshot_frame: bad argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(s->device);
+    MIF_HIP(hipMemcpyAsync(d_descriptors, s->desc + (size_t)frame * s->cap * 128, (size_t)s->cap * 128 * sizeof(float),
+                           hipMemcpyDeviceToDevice, s->stream));
+    MIF_HIP(hipMemcpyAsync(d_count, s->counts + (size_t)frame * CNT_WORDS + CNT_TOTAL, sizeof(int),
+                           hipMemcpyDeviceToDevice, s->stream));
+    return MIF_OK;
+}
+
+int mif_stream_wait_stream(int device, void* waiter, void* signaller)
+{
+    mif::DeviceGuard guard(device);
+    if (!guard.ok) { mif::set_error("mif_stream_wait_stream: cannot select device %d", device); return MIF_ERR_HIP; }
+    hipEvent_t ev = nullptr;
+    MIF_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)signaller);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+    (void)hipEventDestroy(ev);      // released once the recorded work has completed
+    if (e != hipSuccess) { mif::set_error("mif_stream_wait_stream: %s", hipGetErrorString(e)); return MIF_ERR_HIP; }
+    return MIF_OK;
 }
 
 int mif_sift_sync(mif_sift* s)
@@ -1586,7 +1667,10 @@ int mif_sift_set_timing(mif_sift* s, int enable)
     mif::DeviceGuard guard(s->device);
     if (enable && !s->ev_stage[0][0]) {
         for (int o = 0; o < kOctaves; o++)
-            for (int i = 0; i <= MIF_SIFT_STAGES; i++) MIF_HIP(hipEventCreate(&s->ev_stage[o][i]));
+            for (int i = 0; i < 3; i++) {
+                MIF_HIP(hipEventCreate(&s->ev_stage[o][i]));
+                MIF_HIP(hipEventCreate(&s->ev_feat[o][i]));
+            }
     }
     s->timing = enable != 0;
     return MIF_OK;
@@ -1605,7 +1689,10 @@ int mif_sift_stage_times(mif_sift* s, float ms[MIF_SIFT_OCTAVES][MIF_SIFT_STAGES
         for (int i = 0; i < MIF_SIFT_STAGES; i++) {
             ms[o][i] = 0.0f;
             if (s->oct[o].items == 0) continue;
-            MIF_HIP(hipEventElapsedTime(&ms[o][i], s->ev_stage[o][i], s->ev_stage[o][i + 1]));
+            // stages 0, 1: base image and scale space (pyramid phase); 2, 3: detector and
+            // orientation + descriptor (feature phase)
+            if (i < 2) MIF_HIP(hipEventElapsedTime(&ms[o][i], s->ev_stage[o][i], s->ev_stage[o][i + 1]));
+            else MIF_HIP(hipEventElapsedTime(&ms[o][i], s->ev_feat[o][i - 2], s->ev_feat[o][i - 1]));
         }
     return MIF_OK;
 }

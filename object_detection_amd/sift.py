@@ -65,6 +65,18 @@ class SiftExtractor:
         return rc, feats
 
     # --- device-resident path -------------------------------------------------
+    def enqueue_pyramid(self, d_pixels_ptr, nframes=1):
+        """Phase 1 of enqueue(): base images and scale spaces of all octaves."""
+        _lib.check(self._lib.mif_sift_enqueue_pyramid(self._h, C.c_void_p(d_pixels_ptr), nframes))
+
+    def enqueue_features(self, want_descriptors=True):
+        """Phase 2 of enqueue(): detection, orientations, descriptors."""
+        _lib.check(self._lib.mif_sift_enqueue_features(self._h, 1 if want_descriptors else 0))
+
+    def snapshot_frame(self, frame, d_descriptors_ptr, d_count_ptr):
+        _lib.check(self._lib.mif_sift_snapshot_frame(self._h, frame, C.c_void_p(d_descriptors_ptr),
+                                                     C.c_void_p(d_count_ptr)))
+
     def enqueue(self, d_pixels_ptr, nframes=1, want_descriptors=True):
         """d_pixels_ptr: integer device address of nframes frames of uint8 pixels, back to back."""
         _lib.check(self._lib.mif_sift_enqueue(self._h, C.c_void_p(d_pixels_ptr), nframes,

@@ -126,3 +126,41 @@ def test_4k_gray_batch_parity():
         assert np.array_equal(feat.keypoints.view(np.uint32), kp.view(np.uint32))
         assert np.array_equal(feat.orientations.view(np.uint32), ori.view(np.uint32))
         assert np.array_equal(feat.descriptors.view(np.uint32), des.view(np.uint32))
+
+
+def test_two_phase_enqueue_snapshot_and_stream_order():
+    """mif_sift_enqueue_pyramid + mif_sift_enqueue_features equal mif_sift_enqueue; the snapshot of a
+    frame holds its descriptor rows and count; mif_stream_wait_stream orders a foreign stream."""
+    import ctypes as C
+    import torch
+    frames = _frames()
+    B = len(frames)
+    dev = torch.device("cuda:0")
+    px = torch.from_numpy(np.stack(frames)).to(dev)
+    one = oda.SiftExtractor(256, 192, 1, batch=B)
+    one.enqueue(px.data_ptr(), B)
+    two = oda.SiftExtractor(256, 192, 1, batch=B)
+    two.enqueue_pyramid(px.data_ptr(), B)
+    two.enqueue_features(True)
+    cap = two.capacity
+    snap = torch.full((cap, 128), -1.0, dtype=torch.float32, device=dev)
+    cnt = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    two.snapshot_frame(B - 1, snap.data_ptr(), cnt.data_ptr())
+    side = torch.cuda.Stream(device=dev)
+    lib = oda.load_library()
+    _lib.check(lib.mif_stream_wait_stream(0, C.c_void_p(side.cuda_stream), C.c_void_p(two.stream())))
+    with torch.cuda.stream(side):
+        snap2 = snap.clone()            # ordered after the snapshot copy by the wait above
+    side.synchronize()
+    for f in range(B):
+        rc1, a = one.copy_results(f)
+        rc2, b = two.copy_results(f)
+        assert rc1 == rc2 and a.counts == b.counts
+        assert np.array_equal(a.keypoints.view(np.uint32), b.keypoints.view(np.uint32))
+        assert np.array_equal(a.descriptors.view(np.uint32), b.descriptors.view(np.uint32))
+    n = len(b.descriptors)
+    assert int(cnt.cpu()[0]) == n and n > 0
+    assert np.array_equal(snap2.cpu().numpy()[:n], b.descriptors)
+    # the feature phase needs a pending scale space
+    with pytest.raises(_lib.MifError):
+        two.enqueue_features(True)
