@@ -105,14 +105,26 @@ MIF_HD float mif_atan01(float a)
     return y0 + p;
 }
 
-// atan2(y, x) in [-pi, pi]; atan2(0, 0) = 0.
+// atan2(y, x) in [-pi, pi]; atan2(0, 0) = 0. One division: with mn <= mx the magnitudes,
+// atan(mn / mx) = atan(a) for a = mn / mx <= tan(pi/8), and pi/4 + atan((mn - mx) / (mn + mx))
+// above, so the reduced argument is formed before dividing.
 MIF_HD float mif_atan2f(float y, float x)
 {
     const float ax = mif_fabsf(x), ay = mif_fabsf(y);
     const float mx = ax > ay ? ax : ay;
     const float mn = ax > ay ? ay : ax;
     if (!(mx > 0.0f)) return 0.0f;
-    float r = mif_atan01(mn / mx);
+    const bool upper = mn > 0.4142135679721832275390625f * mx;    // mn / mx > tan(pi/8)
+    const float num = upper ? mn - mx : mn;
+    const float den = upper ? mn + mx : mx;
+    const float a = num / den;                                    // |a| <= tan(pi/8)
+    const float z = a * a;
+    float p = 8.05374449538e-2f;
+    p = __builtin_fmaf(p, z, -1.38776856032e-1f);
+    p = __builtin_fmaf(p, z, 1.99777106478e-1f);
+    p = __builtin_fmaf(p, z, -3.33329491539e-1f);
+    p = __builtin_fmaf(p * z, a, a);
+    float r = upper ? MIF_PIO4_F + p : p;
     if (ay > ax) r = MIF_PIO2_F - r;
     if (x < 0.0f) r = MIF_PI_F - r;
     return y < 0.0f ? -r : r;
