@@ -311,7 +311,7 @@ def main():
             "stage_ms_per_batch": {"base": float(stage[:, 0].sum()), "scale_space": blur_ms,
                                    "detector": float(stage[:, 2].sum()), "orient_desc": float(stage[:, 3].sum())},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     barrier()
