@@ -7,6 +7,8 @@ matrix cores + running top-2 + exact distances of the winners). Prints one JSON
 line with matches/s and the matrix-core utilisation (2 * dim * nq * nd flop).
 
 python tools/bench_match.py --nq 65536 --nd 262144 --steps 3
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_match.py \
+    --nq 1000000 --nd 1000000      (database sharded over the ranks, RCCL all-gather of the candidates)
 """
 import argparse
 import json
@@ -32,39 +34,91 @@ def main():
     import numpy as np
     import torch
     import object_detection_amd as oda
+    from object_detection_amd.distributed import merge_top2, shard_range
     from synth import sift_like_descriptors
-    dev = torch.device("cuda", 0)
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("BENCH_BACKEND", "nccl")      # gloo: several ranks may share a GPU (rehearsal)
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+
+    # the same seeded data on every rank; a rank keeps the queries and its contiguous database shard
     rng = np.random.default_rng(7)
     base = sift_like_descriptors(min(args.nd, 65536), seed=7, dim=args.dim)
     reps = (args.nd + len(base) - 1) // len(base)
     db = np.concatenate([np.roll(base, r, axis=1) for r in range(reps)])[:args.nd]
     perm = rng.permutation(args.nd)[:args.nq] if args.nq <= args.nd else rng.integers(0, args.nd, args.nq)
     q = np.clip(db[perm] + rng.normal(0, 8, (args.nq, args.dim)).astype(np.float32), 0, 255).astype(np.float32)
+    lo, hi = shard_range(args.nd, rank, world)
+    rows = hi - lo
     tq = torch.from_numpy(np.ascontiguousarray(q)).to(dev)
-    td = torch.from_numpy(np.ascontiguousarray(db)).to(dev)
-    m = oda.Matcher(args.nq, args.nd, device=0)
+    td = torch.from_numpy(np.ascontiguousarray(db[lo:hi])).to(dev)
+    del db
+    m = oda.Matcher(args.nq, max(rows, 1), device=local_rank)
     idx = torch.zeros((args.nq, 2), dtype=torch.int32, device=dev)
-    dist = torch.zeros((args.nq, 2), dtype=torch.float32, device=dev)
+    dst = torch.zeros((args.nq, 2), dtype=torch.float32, device=dev)
+    score = torch.zeros((args.nq, 2), dtype=torch.float32, device=dev)
+    pair = [dict(q=tq.data_ptr(), db=td.data_ptr(), idx2=idx.data_ptr(), dist2=dst.data_ptr(),
+                 score2=score.data_ptr())]
+    stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
-        m.top2_device(tq.data_ptr(), args.nq, td.data_ptr(), args.nd, args.dim, args.dim, idx.data_ptr(),
-                      dist.data_ptr())
+        """Local search of the shard, then (world > 1) the exchange of the per-rank candidates
+        (score, global index, distance: 24 B per query and rank) and the merge on every rank."""
+        m.top2_batch_device(pair, args.nq, rows, args.dim, args.dim, 0, stream=stream)
+        if world == 1:
+            return idx, dst
+        gidx = torch.where(idx >= 0, idx + lo, idx)
+        packed = torch.stack([score, gidx.view(torch.float32), dst], dim=2)
+        if backend != "nccl":
+            packed = packed.cpu()
+        gathered = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(gathered, packed)
+        allp = torch.stack(gathered).to(dev)
+        return merge_top2(allp[..., 0], allp[..., 1].contiguous().view(torch.int32), allp[..., 2])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        wi, wd = step()
     torch.cuda.synchronize()
+    barrier()
     dt = (time.perf_counter() - t0) / args.steps
-    hit = float((idx[:, 0].cpu().numpy() == perm).mean()) if args.nq <= args.nd else None
-    flops = 2.0 * args.dim * args.nq * args.nd
-    print(json.dumps({"metric": "descriptor matches/sec", "value": args.nq / dt, "unit": "matches/s",
-                      "nq": args.nq, "nd": args.nd, "dim": args.dim, "ms_per_step": dt * 1e3,
-                      "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS},
-                      "true_neighbour_recovered": hit}))
+    t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        hit = float((wi[:, 0].cpu().numpy() == perm).mean()) if args.nq <= args.nd else None
+        flops = 2.0 * args.dim * args.nq * args.nd
+        print(json.dumps({"metric": "descriptor matches/sec", "value": args.nq / dt, "unit": "matches/s",
+                          "n_gpus": world, "nq": args.nq, "nd": args.nd, "dim": args.dim, "ms_per_step": dt * 1e3,
+                          "scaling": "strong", "parallelism": "database rows sharded over %d GPU(s), all-gather of "
+                          "top-2 candidates" % world,
+                          "roofline": {"bound": "mfma", "achieved": flops / dt / 1e12,
+                                       "peak": MFMA_F32_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                                       "frac": flops / dt / 1e12 / (MFMA_F32_PEAK_TFLOPS * world)},
+                          "true_neighbour_recovered": hit}), flush=True)
+    barrier()
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
