@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--channels", type=int, default=3, choices=[1, 3])
+    ap.add_argument("--no-match", action="store_true",
+                    help="extraction only (the 4K batch configuration: --width 3840 --height 2160 --channels 1)")
     ap.add_argument("--serial", action="store_true",
                     help="run the matcher of a batch after its feature phase instead of beside the next one's")
     return ap.parse_args()
@@ -50,14 +53,14 @@ def parse_args():
 
 def _frame(job):
     from synth import blob_image
-    width, height, seed, t = job
-    return blob_image(width, height, seed=seed, channels=3, shift=(2 * t, t))
+    width, height, seed, t, channels = job
+    return blob_image(width, height, seed=seed, channels=channels, shift=(2 * t, t))
 
 
-def make_frames(width, height, batch, rank):
+def make_frames(width, height, batch, rank, channels=3):
     """Frame t = the seeded blob field translated by (2t, t). Rendered by a few worker processes
     (numpy only; called before anything touches the GPU)."""
-    jobs = [(width, height, 1234 + 100 * rank, t) for t in range(batch)]
+    jobs = [(width, height, 1234 + 100 * rank, t, channels) for t in range(batch)]
     workers = min(8, batch)
     if workers > 1:
         import multiprocessing as mp
@@ -81,13 +84,14 @@ class Pipeline:
     bound) shares the GPU with the matcher (matrix cores). With serial=True the matcher of batch k
     runs after features(k) instead and nothing overlaps."""
 
-    def __init__(self, oda, torch, dev_index, width, height, batch, serial=False):
+    def __init__(self, oda, torch, dev_index, width, height, batch, serial=False, channels=3, match=True):
         from object_detection_amd import _lib
         self._lib, self.lib = _lib, oda.load_library()
         self.serial = serial
         self.oda, self.torch, self.B, self.dev_index = oda, torch, batch, dev_index
         self.dev = torch.device("cuda", dev_index)
-        self.h = [oda.SiftExtractor(width, height, 3, device=dev_index, batch=batch) for _ in range(2)]
+        self.match = match
+        self.h = [oda.SiftExtractor(width, height, channels, device=dev_index, batch=batch) for _ in range(2)]
         self.cap = self.h[0].capacity
         self.m = oda.Matcher(self.cap, self.cap, device=dev_index, max_pairs=batch)
         self.mstream = torch.cuda.Stream(device=self.dev)
@@ -129,6 +133,8 @@ class Pipeline:
                                                         ctypes.c_void_p(signaller)))
 
     def _match(self, k):
+        if not self.match:
+            return
         self.m.top2_batch_device(self._pairs(k), self.cap, self.cap, 127, 128, self._lib.FILTER_SIFT,
                                  stream=self.mstream.cuda_stream)
 
@@ -166,19 +172,19 @@ class Pipeline:
         self.mstream.synchronize()
 
 
-def cpu_baseline(frames, budget_s):
+def cpu_baseline(frames, budget_s, match=True):
     """CPU restatement of the reference's -f 0 path (oracle/, OpenMP) on a bounded sample of the same
     frames: extraction of every sampled frame plus matching against the previous sampled frame."""
     import oracle_lib as orc
     import object_detection_amd as oda
-    n, h, w, _ = frames.shape
-    S = orc.SiftOracle(w, h, 3)
+    n, h, w = frames.shape[:3]
+    S = orc.SiftOracle(w, h, 1 if frames.ndim == 3 else frames.shape[3])
     prev = None
     done, t0 = 0, time.perf_counter()
     while done < max(2, min(n, 64)):
         S.run(frames[done % n])
         des = S.all_features()[3]
-        if prev is not None and len(des) and len(prev):
+        if match and prev is not None and len(des) and len(prev):
             idx, dist = orc.match_top2(oda.pack_sift_rows(des), oda.pack_sift_rows(prev))
             mn = min(100.0, float(dist[:, 0].min()))
             _ = dist[:, 0] <= max(2.5 * mn, 0.35)
@@ -188,8 +194,9 @@ def cpu_baseline(frames, budget_s):
             break
     dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "frames/s", "cores": orc.lib().orc_get_threads(), "kind": "port",
-            "sample": "%d frames %dx%d BGR, extract + match vs previous frame, OpenMP restatement of the "
-                      "reference -f 0 path (oracle/)" % (done, w, h)}
+            "sample": "%d frames %dx%d %s, %s, OpenMP restatement of the reference -f 0 path (oracle/)"
+                      % (done, w, h, "gray" if frames.ndim == 3 else "BGR",
+                         "extract + match vs previous frame" if match else "extraction only")}
 
 
 def main():
@@ -197,7 +204,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    frames_np = make_frames(args.width, args.height, args.batch, rank)      # before the GPU is initialised
+    frames_np = make_frames(args.width, args.height, args.batch, rank, args.channels)      # before the GPU is initialised
     import torch
     import object_detection_amd as oda
     if not torch.cuda.is_available():
@@ -220,7 +227,8 @@ def main():
             dist.barrier()
 
     frames = torch.from_numpy(frames_np).to(torch.device("cuda", local_rank))
-    pipe = Pipeline(oda, torch, local_rank, args.width, args.height, args.batch, serial=args.serial)
+    pipe = Pipeline(oda, torch, local_rank, args.width, args.height, args.batch, serial=args.serial,
+                    channels=args.channels, match=not args.no_match)
 
     for _ in range(args.warmup):
         pipe.step(frames.data_ptr())
@@ -279,7 +287,10 @@ def main():
     if rank == 0:
         frames_total = args.batch * args.steps * world
         out = {
-            "metric": "1080p SIFT extract+match frames/sec",
+            "metric": "1080p SIFT extract+match frames/sec"
+                      if (args.width, args.height, args.no_match) == (1920, 1080, False)
+                      else "%dx%d SIFT %s frames/sec" % (args.width, args.height,
+                                                          "extraction" if args.no_match else "extract+match"),
             "value": frames_total / dt_max,
             "unit": "frames/s",
             "n_gpus": world,
@@ -291,8 +302,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "SIFT extract + match-vs-previous-frame on a synthetic %dx%d BGR sequence "
-                                   "(stand-in for basketball.mp4, BASELINE.json configs[2])" % (args.width, args.height),
+            "config": {"workload": ("SIFT extract + match-vs-previous-frame on a synthetic %dx%d BGR sequence "
+                                    "(stand-in for basketball.mp4, BASELINE.json configs[2])" % (args.width, args.height))
+                       if (not args.no_match and args.channels == 3) else
+                       ("SIFT %s on a synthetic %dx%dx%d sequence" % ("extraction" if args.no_match else
+                                                                       "extract + match", args.width, args.height,
+                                                                       args.channels)),
                        "frames_per_step": args.batch, "octaves": 3, "levels": 6,
                        "pipeline": "matcher after each batch" if args.serial else
                                    "matcher of batch k-1 beside the feature phase of batch k",
@@ -312,7 +327,7 @@ def main():
                                    "detector": float(stage[:, 2].sum()), "orient_desc": float(stage[:, 3].sum())},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_seconds, match=not args.no_match)
         print(json.dumps(out), flush=True)
     barrier()
     if dist is not None:
