@@ -216,3 +216,45 @@ def test_up_scale_equals_pixel_replication(channels):
 def test_up_scale_odd_size_geometry():
     up = orc.SiftOracle(65, 47, 1, up_scale=True)
     assert [up.dims(o) for o in range(3)] == [(130, 94), (65, 47), (32, 23)]
+
+
+def test_orientation_and_descriptor_against_second_restatement():
+    """A few keypoints of every octave: the checker's orientation and descriptor must equal, bit for bit,
+    the separate Python restatement of kOrientation / kDescriptor / kNormalize (tests/ref_restatement.py)."""
+    import ref_restatement as ref
+    img = blob_image(128, 96, seed=5)
+    S = orc.SiftOracle(128, 96)
+    assert S.run(img) == 0
+    checked = 0
+    for o in range(3):
+        w, h = S.dims(o)
+        pyr = S.pyramid(o).reshape(-1).copy()
+        kps, ori, des = S.keypoints(o), S.orientations(o), S.descriptors(o)
+        for i in range(min(4, len(kps))):
+            th = ref.orientation(pyr, w, h, kps[i], o)
+            assert th.view(np.uint32) == ori[i].view(np.uint32), (o, i, float(th), float(ori[i]))
+            d = ref.descriptor(pyr, w, h, kps[i], ori[i], o)
+            assert np.array_equal(d.view(np.uint32), des[i].view(np.uint32)), (o, i)
+            checked += 1
+    assert checked >= 6
+
+
+def test_detector_against_second_restatement():
+    """Every octave of two small images (one of them overflowing the list limit): the checker's keypoint
+    list must equal, bit for bit and in order, the separate Python restatement of kDetector
+    (tests/ref_restatement.py)."""
+    import ref_restatement as ref
+    from synth import dense_image
+    total = 0
+    for img in (blob_image(200, 150, seed=9), dense_image(160, 120, seed=3)):
+        hh, ww = img.shape
+        S = orc.SiftOracle(ww, hh)
+        S.run(img, want_descriptors=False)
+        for o in range(3):
+            w, h = S.dims(o)
+            kp = ref.detector(S.dog(o), w, h, o, S.max_features(o))
+            got = S.keypoints(o)
+            assert len(kp) == len(got), (o, len(kp), len(got))
+            assert np.array_equal(kp.view(np.uint32), got.view(np.uint32)), o
+            total += len(kp)
+    assert total > 200
