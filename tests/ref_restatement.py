@@ -270,3 +270,95 @@ def detector(dog, w, h, oid, max_feat):
                     sig = f32(f64(1.6) * f64(f32(L.orc_math_exp2f(float((f32(ts) + oz) / f32(3))))))
                     out.append(((f32(tx) + ox) * p2, (f32(ty) + oy) * p2, sig, f32(ts)))
     return np.array(out[:max_feat], np.float32).reshape(-1, 4)
+
+
+# ------------------------------------------------------------------------------------------------ SURF
+SURF_FILTER_MAP = [[0, 1, 2, 3], [1, 3, 4, 5], [3, 5, 6, 7]]      # ccl_surf.cpp:109-113, OCTAVES = 3
+SURF_THRES = f32(0.0001)                                          # surf_constants.h
+
+
+def surf_select_points(layers, max_points=8000):
+    """selectIpoints + non_max_supression (ccl_surf.cpp:285-343, nonMaxSuppression_kernel.cl:79-364) in
+    plain Python, points in (launch, row, column) order (the reference's order is that of an atomic
+    counter). layers: list of (responses [h, w] float32, laplacians [h, w] int32, step, filter).
+    Returns a list of (x, y, scale, laplacian)."""
+    out = []
+
+    def resp(layer, c, r, scale):                 # getResponse: layer[r*scale*width + c*scale]
+        return layer[0][r * scale, c * scale]
+
+    for o in range(3):
+        for i in range(2):
+            b = layers[SURF_FILTER_MAP[o][i]]
+            m = layers[SURF_FILTER_MAP[o][i + 1]]
+            t = layers[SURF_FILTER_MAP[o][i + 2]]
+            tH, tW = t[0].shape
+            mH, mW = m[0].shape
+            bW = b[0].shape[1]
+            tStep, tFilter, mFilter, bFilter = t[2], t[3], m[3], b[3]
+            border = (tFilter + 1) // (2 * tStep)
+            mS, bS = mW // tW, bW // tW
+            # the launch covers the middle layer's size rounded up to 16; everything outside the top
+            # layer's interior is rejected first
+            for r in range(-(-mH // 16) * 16):
+                if r <= border or r >= tH - border:
+                    continue
+                for c in range(-(-mW // 16) * 16):
+                    if c <= border or c >= tW - border:
+                        continue
+                    cand = resp(m, c, r, mS)
+                    if cand < SURF_THRES:
+                        continue
+                    lm = resp(t, c - 1, r - 1, 1)
+                    for (dc, dr) in ((0, -1), (1, -1), (-1, 0), (0, 0), (1, 0), (-1, 1), (0, 1), (1, 1)):
+                        lm = max(lm, resp(t, c + dc, r + dr, 1))
+                    for (dc, dr) in ((-1, -1), (0, -1), (1, -1), (-1, 0), (0, 0), (1, 0), (-1, 1), (0, 1), (1, 1)):
+                        lm = max(lm, resp(b, c + dc, r + dr, bS))
+                    for (dc, dr) in ((-1, -1), (0, -1), (1, -1), (-1, 0), (1, 0), (-1, 1), (0, 1), (1, 1)):
+                        lm = max(lm, resp(m, c + dc, r + dr, mS))
+                    if lm > cand:
+                        continue
+                    # interpolateExtremum
+                    two, four = f32(2.0), f32(4.0)
+                    dx = (resp(m, c + 1, r, mS) - resp(m, c - 1, r, mS)) / two
+                    dy = (resp(m, c, r + 1, mS) - resp(m, c, r - 1, mS)) / two
+                    ds = (resp(t, c, r, 1) - resp(b, c, r, bS)) / two
+                    v = resp(m, c, r, mS)
+                    dxx = (resp(m, c + 1, r, mS) + resp(m, c - 1, r, mS)) - two * v
+                    dyy = (resp(m, c, r + 1, mS) + resp(m, c, r - 1, mS)) - two * v
+                    dss = (resp(t, c, r, 1) + resp(b, c, r, bS)) - two * v
+                    dxy = (((resp(m, c + 1, r + 1, mS) - resp(m, c - 1, r + 1, mS)) - resp(m, c + 1, r - 1, mS))
+                           + resp(m, c - 1, r - 1, mS)) / four
+                    dxs = (((resp(t, c + 1, r, 1) - resp(t, c - 1, r, 1)) - resp(b, c + 1, r, bS))
+                           + resp(b, c - 1, r, bS)) / four
+                    dys = (((resp(t, c, r + 1, 1) - resp(t, c, r - 1, 1)) - resp(b, c, r + 1, bS))
+                           + resp(b, c, r - 1, bS)) / four
+                    H0, H1, H2, H3, H4, H5, H6, H7, H8 = dxx, dxy, dxs, dxy, dyy, dys, dxs, dys, dss
+                    det = (H0 * (H4 * H8 - H7 * H5) - H1 * (H3 * H8 - H5 * H6)) + H2 * (H3 * H7 - H4 * H6)
+                    inv = f32(1.0) / det
+                    i0 = (H4 * H8 - H7 * H5) * inv
+                    i1 = -(H3 * H8 - H5 * H6) * inv
+                    i2 = (H3 * H7 - H6 * H4) * inv
+                    i3 = -(H1 * H8 - H2 * H7) * inv
+                    i4 = (H0 * H8 - H2 * H6) * inv
+                    i5 = -(H0 * H7 - H6 * H1) * inv
+                    i6 = (H1 * H5 - H2 * H4) * inv
+                    i7 = -(H0 * H5 - H3 * H2) * inv
+                    i8 = (H0 * H4 - H3 * H1) * inv
+                    neg = f32(-1.0)
+                    xc = i0 * dx * neg
+                    xc = xc + i1 * dy * neg
+                    xc = xc + i2 * ds * neg
+                    xr = i3 * dx * neg
+                    xr = xr + i4 * dy * neg
+                    xr = xr + i5 * ds * neg
+                    xi = i6 * dx * neg
+                    xi = xi + i7 * dy * neg
+                    xi = xi + i8 * ds * neg
+                    if abs(xi) < 0.5 and abs(xr) < 0.5 and abs(xc) < 0.5:
+                        x = (f32(c) + xc) * f32(tStep)
+                        y = (f32(r) + xr) * f32(tStep)
+                        sc = f32(0.1333) * (f32(mFilter) + xi * f32(mFilter - bFilter))
+                        lap = int(m[1][r * mS, c * mS])
+                        out.append((x, y, sc, lap))
+    return out[:max_points]

@@ -97,3 +97,27 @@ def test_surf_oracle_matches_golden(name):
     S.run(img)
     assert np.array_equal(S.points().view(np.uint32), gold[name].view(np.uint32))
     assert np.array_equal(S.integral().view(np.uint32).sum(dtype=np.uint64), gold[name + "_intsum"])
+
+
+@pytest.mark.parametrize("name", ["box", "scene"])
+def test_point_selection_against_second_restatement(name):
+    """Positions, scales and laplacians of all interest points, in order, against the separate Python
+    restatement of selectIpoints / non_max_supression (tests/ref_restatement.py), bit for bit."""
+    import ref_restatement as ref
+    img = orc.read_pnm(os.path.join(orc.GOLDEN, name + ".pgm"))
+    h, w = img.shape
+    S = orc.SurfOracle(w, h)
+    S.run(img)
+    layers = []
+    for i in range(8):
+        lw, lh, step, flt = S.layer_info(i)
+        r, l = S.layer(i)
+        layers.append((r, l, step, flt))
+    want = ref.surf_select_points(layers)
+    got = S.points()
+    assert len(want) == len(got) == S.count() and len(want) > 50
+    for (x, y, sc, lap), row in zip(want, got):
+        assert np.float32(x).view(np.uint32) == row[0].view(np.uint32)
+        assert np.float32(y).view(np.uint32) == row[1].view(np.uint32)
+        assert np.float32(sc).view(np.uint32) == row[2].view(np.uint32)
+        assert lap == int(row[4])
