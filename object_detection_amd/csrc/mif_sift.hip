@@ -943,17 +943,23 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
         // The gather of the next window pixel is issued before the current one is
         // processed (whether or not it will pass the cell test), so its latency overlaps
         // the arithmetic.
-        int yn = lid / wx + ymin;
+        // The coordinates also run as floats (small integers: adding 8 or 1 is exact) and the
+        // pixel as a running pointer, which saves the conversions and the index arithmetic.
         int xn = lid % wx + xmin;
-        float2 gnext = (lid < loops) ? img[yn * w + xn] : make_float2(0.0f, 0.0f);
+        const int y0n = lid / wx + ymin;
+        float fxn = (float)xn, fyn = (float)y0n;
+        const float fwx = (float)wx;
+        const float2* pn = img + (y0n * w + xn);
+        const int row_step = w - wx;            // pointer correction when a row of the window ends
+        float2 gnext = (lid < loops) ? *pn : make_float2(0.0f, 0.0f);
         for (int i = lid; i < loops; i += 8) {
-            const int xx = xn, yy = yn;
+            const float fx = fxn, fy = fyn;
             const float2 g2 = gnext;
-            xn += 8;
-            while (xn > xmax) { xn -= wx; yn++; }
-            if (i + 8 < loops) gnext = img[yn * w + xn];
-            float dx = (float)xx - ptx;
-            float dy = (float)yy - pty;
+            xn += 8; fxn += 8.0f; pn += 8;
+            while (xn > xmax) { xn -= wx; fxn -= fwx; fyn += 1.0f; pn += row_step; }
+            if (i + 8 < loops) gnext = *pn;
+            float dx = fx - ptx;
+            float dy = fy - pty;
             const float nx = crspt * dx + srspt * dy;
             const float ny = crspt * dy - srspt * dx;
             const float nxn = mif_fabsf(nx), nyn = mif_fabsf(ny);
