@@ -164,127 +164,152 @@ __global__ void k_decimate(const float* __restrict__ src, size_t src_stride, flo
 // short of the filter width, sift.cpp:222,238) in ascending order as an fmaf
 // chain starting from 0, with zeros outside the image.
 //
-// A block of 256 threads owns a 64 x 64 output tile and is bound by vector
-// instruction issue, not by LDS or HBM, so every phase is shaped to spend as
-// few instructions per pixel as possible:
-//  * staging: a wave takes one row of the (64+2FR-1)^2 input window per step
-//    (row index and bounds are wave-uniform, lanes run along x), issues all its
-//    loads before the first LDS store, and stores TRANSPOSED (odd pitch);
-//  * horizontal pass: lanes run along y; a thread owns rows r and r + H2 and an
-//    8-column chunk, keeps the 8+2FR-1 input pairs in registers and evaluates
-//    the two rows' chains side by side with packed FMAs (each half of a packed
-//    FMA is an IEEE fmaf, so the chains are the same as the scalar ones);
-//  * vertical pass: a thread owns two adjacent columns and 8 rows, reads the
-//    horizontal result as 8-byte pairs and again uses packed FMAs.
+// A block of 256 threads owns a 64 x 64 output tile. Its speed depends on how
+// many blocks a CU holds (the memory phases of some hide behind the arithmetic
+// of others) and on the instructions spent per pixel, so
+//  * ONE LDS array holds first the (64+2FR-1)^2 input window, transposed, and
+//    then the horizontal pass's result: every thread moves its horizontal
+//    window (and the window's centre, which the DoG needs) into registers
+//    before the first result is written;
+//  * staging: a wave takes one row of the window per step (row index and bounds
+//    are wave-uniform, lanes run along x) with a scalar row base, issues all
+//    its loads before the first LDS store, and stores TRANSPOSED (odd pitch);
+//    rows outside the image are read from a row of zeros;
+//  * horizontal pass: lanes run along y, a thread owns one row and 22 columns,
+//    so that all four waves carry the same load;
+//  * vertical pass: a thread owns two adjacent columns and 8 rows and evaluates
+//    the two columns' chains side by side with packed FMAs (each half of a
+//    packed FMA is an IEEE fmaf, so the chains are the same as the scalar ones).
 // All LDS accesses of the passes have unit or odd lane stride.
+// Tiles (frame-major, then raster order) are cut into 8 contiguous ranges, one
+// per XCD (consecutive blocks go to consecutive XCDs), so that neighbouring
+// tiles, which share halo rows and columns, meet in the same L2.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int FR, bool DOG>
 __global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ src, size_t src_stride,
                                                     float* __restrict__ dst, float* __restrict__ dog,
-                                                    size_t pyr_stride, size_t dog_stride, int w, int h, Taps taps)
+                                                    size_t pyr_stride, size_t dog_stride, int w, int h, Taps taps,
+                                                    int tiles_x, int tiles_y, int ntiles,
+                                                    const float* __restrict__ zero_row)
 {
-    src += (size_t)blockIdx.z * src_stride;
-    dst += (size_t)blockIdx.z * pyr_stride;
-    if (DOG) dog += (size_t)blockIdx.z * dog_stride;
     constexpr int TW = kBlurTile, TH = kBlurTile;
-    constexpr int P = 8, R = 8;
+    constexpr int R = 8;                         // rows of a vertical-pass thread
+    constexpr int HC = 22, HS = 21;              // columns of a horizontal-pass thread, chunk spacing
     constexpr int NT = 2 * FR;                   // taps applied
     constexpr int EW = TW + NT - 1;              // staged columns
     constexpr int EH = TH + NT - 1;              // staged rows (odd)
-    constexpr int H2 = (EH + 1) / 2;             // a horizontal-pass thread owns rows r and r + H2
     constexpr int PT = EH | 1;                   // odd pitch of the transposed input
-    constexpr int PH = TW + 2;                   // even pitch of the H-pass result (8-byte aligned pairs)
+    constexpr int PH = TW + 1;                   // odd pitch of the horizontal pass's result
+    constexpr int kSteps = (EH + 3) / 4;         // staged rows per wave
     static_assert(TW == 64 && TH == 64, "thread mappings below assume a 64 x 64 tile");
     static_assert(NT <= kMaxTaps && EW - 64 <= 64, "tap radius too large");
+    static_assert(3 * EH <= 256 && 2 * HS + HC == TW, "horizontal pass: three chunks of one row per thread");
 
-    __shared__ float s_in[EW * PT + 1];          // + 1: the row r + H2 = EH of the last column is read, not used
-    __shared__ __align__(8) float s_h[EH * PH];
+    __shared__ float s_buf[(EW * PT > EH * PH) ? EW * PT : EH * PH];
+    float* const s_in = s_buf;                   // [column][row] of the input window
+    float* const s_h = s_buf;                    // [row][column] after the horizontal pass
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x0 = blockIdx.x * TW;
-    const int y0 = blockIdx.y * TH;
 
-    // stage the input window, zero outside the image
+    // block -> tile
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int t = xcd * per_xcd + (int)(blockIdx.x >> 3);
+    if (t >= min((xcd + 1) * per_xcd, ntiles)) return;       // uniform over the block
+    const int tiles_xy = tiles_x * tiles_y;
+    const int z = t / tiles_xy;
+    const int rem = t - z * tiles_xy;
+    const int ty = rem / tiles_x;
+    const int x0 = (rem - ty * tiles_x) * TW, y0 = ty * TH;
+    src += (size_t)z * src_stride;
+    dst += (size_t)z * pyr_stride;
+    if (DOG) dog += (size_t)z * dog_stride;
+
+    // stage the input window
     {
-        constexpr int kSteps = (EH + 3) / 4;
         const int gx0 = x0 - FR + lane, gx1 = gx0 + 64;
         const bool in0 = gx0 >= 0 && gx0 < w;
         const bool in1 = gx1 >= 0 && gx1 < w;
-        const int cx0 = min(max(gx0, 0), w - 1), cx1 = min(max(gx1, 0), w - 1);
+        // the second load covers the columns beyond 64; its idle lanes repeat the last one
+        const unsigned boff0 = 4u * (unsigned)min(max(gx0, 0), w - 1);
+        const unsigned boff1 = 4u * (unsigned)min(max(min(gx1, x0 - FR + EW - 1), 0), w - 1);
         float st0[kSteps], st1[kSteps];
 #pragma unroll
         for (int it = 0; it < kSteps; it++) {
-            const int gy = min(max(y0 - FR + wv + 4 * it, 0), h - 1);
-            st0[it] = src[(size_t)gy * w + cx0];
-        }
-        if (lane < EW - 64) {
-#pragma unroll
-            for (int it = 0; it < kSteps; it++) {
-                const int gy = min(max(y0 - FR + wv + 4 * it, 0), h - 1);
-                st1[it] = src[(size_t)gy * w + cx1];
-            }
+            const int gy = y0 - FR + wv + 4 * it;
+            const int gyc = min(max(gy, 0), h - 1);
+            const float* inside = src + (unsigned)(gyc * w);
+            const char* rowp = (const char*)((gy == gyc) ? inside : zero_row);
+            st0[it] = *(const float*)(rowp + boff0);
+            st1[it] = *(const float*)(rowp + boff1);
         }
 #pragma unroll
         for (int it = 0; it < kSteps; it++) {
             const int ly = wv + 4 * it;
-            const int gy = y0 - FR + ly;
-            const bool iny = gy >= 0 && gy < h;
-            if (ly < EH) s_in[lane * PT + ly] = (iny && in0) ? st0[it] : 0.0f;
+            if (4 * it + 3 < EH || ly < EH) s_in[lane * PT + ly] = in0 ? st0[it] : 0.0f;
         }
         if (lane < EW - 64) {
 #pragma unroll
             for (int it = 0; it < kSteps; it++) {
                 const int ly = wv + 4 * it;
-                const int gy = y0 - FR + ly;
-                const bool iny = gy >= 0 && gy < h;
-                if (ly < EH) s_in[(64 + lane) * PT + ly] = (iny && in1) ? st1[it] : 0.0f;
+                if (4 * it + 3 < EH || ly < EH) s_in[(64 + lane) * PT + ly] = in1 ? st1[it] : 0.0f;
             }
         }
     }
     __syncthreads();
 
-    // horizontal pass
-    for (int item = tid; item < (TW / P) * H2; item += 256) {
-        const int chunk = item / H2;
-        const int row = item - chunk * H2;
-        v2f win[P + NT - 1];
+    // vertical-pass mapping: columns 2 xp, 2 xp + 1, rows R yc .. R yc + R - 1
+    const int xp = tid & 31;
+    const int yc = tid >> 5;
+    v2f centre[R];
+    if (DOG) {
 #pragma unroll
-        for (int j = 0; j < P + NT - 1; j++) {
-            const float* p = &s_in[(chunk * P + j) * PT + row];
-            win[j] = (v2f){p[0], p[H2]};
+        for (int r = 0; r < R; r++) {
+            const float* c = &s_in[(2 * xp + FR) * PT + (yc * R + r + FR)];
+            centre[r] = (v2f){c[0], c[PT]};
         }
-        float* o0 = &s_h[row * PH + chunk * P];
-        const bool two = row + H2 < EH;
-        // the P chains advance together: consecutive packed FMAs are independent
-        v2f acc[P];
+    }
+
+    // horizontal pass: chunks start at columns 0, 21, 42; the shared columns are written
+    // twice with the same value
+    const bool hactive = tid < 3 * EH;
+    const int chunk = tid / EH;
+    const int row = tid - chunk * EH;
+    float hacc[HC];
+    {
+        float win[HC + NT - 1];
+        if (hactive) {
 #pragma unroll
-        for (int p = 0; p < P; p++) acc[p] = (v2f){0.0f, 0.0f};
-#pragma unroll
-        for (int k = 0; k < NT; k++) {
-            const v2f t = (v2f){taps.t[k], taps.t[k]};
-#pragma unroll
-            for (int p = 0; p < P; p++) acc[p] = __builtin_elementwise_fma(t, win[p + k], acc[p]);
-            __builtin_amdgcn_sched_barrier(0);      // keep the chains interleaved
+            for (int j = 0; j < HC + NT - 1; j++) win[j] = s_in[(chunk * HS + j) * PT + row];
         }
+        __syncthreads();                         // the window is in registers everywhere: s_buf is free
+        if (hactive) {
 #pragma unroll
-        for (int p = 0; p < P; p++) o0[p] = acc[p].x;
-        if (two) {
+            for (int p = 0; p < HC; p++) hacc[p] = 0.0f;
 #pragma unroll
-            for (int p = 0; p < P; p++) o0[H2 * PH + p] = acc[p].y;
+            for (int k = 0; k < NT; k++) {
+#pragma unroll
+                for (int p = 0; p < HC; p++) hacc[p] = fmaf(taps.t[k], win[p + k], hacc[p]);
+                __builtin_amdgcn_sched_barrier(0);      // keep the chains interleaved
+            }
+            float* o0 = &s_h[row * PH + chunk * HS];
+#pragma unroll
+            for (int p = 0; p < HC; p++) o0[p] = hacc[p];
         }
     }
     __syncthreads();
 
     // vertical pass
     {
-        const int xp = tid & 31;
-        const int yc = tid >> 5;
         v2f win[R + NT - 1];
 #pragma unroll
-        for (int j = 0; j < R + NT - 1; j++) win[j] = *(const v2f*)&s_h[(yc * R + j) * PH + 2 * xp];
+        for (int j = 0; j < R + NT - 1; j++) {
+            const float* p = &s_h[(yc * R + j) * PH + 2 * xp];
+            win[j] = (v2f){p[0], p[1]};
+        }
         const int gx = x0 + 2 * xp;
         const bool pair = gx + 1 < w && (w & 1) == 0;     // 8-byte aligned two-pixel stores
         v2f acc[R];
@@ -292,9 +317,9 @@ __global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ sr
         for (int r = 0; r < R; r++) acc[r] = (v2f){0.0f, 0.0f};
 #pragma unroll
         for (int k = 0; k < NT; k++) {
-            const v2f t = (v2f){taps.t[k], taps.t[k]};
+            const v2f tk = (v2f){taps.t[k], taps.t[k]};
 #pragma unroll
-            for (int r = 0; r < R; r++) acc[r] = __builtin_elementwise_fma(t, win[r + k], acc[r]);
+            for (int r = 0; r < R; r++) acc[r] = __builtin_elementwise_fma(tk, win[r + k], acc[r]);
             __builtin_amdgcn_sched_barrier(0);
         }
         // pin the results here, or each chain is sunk into its row's bounds check below
@@ -306,10 +331,7 @@ __global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ sr
             if (gy < h && gx < w) {
                 const size_t at = (size_t)gy * w + gx;
                 v2f d = acc[r];
-                if (DOG) {
-                    const float* c = &s_in[(2 * xp + FR) * PT + (yc * R + r + FR)];
-                    d = acc[r] - (v2f){c[0], c[PT]};
-                }
+                if (DOG) d = acc[r] - centre[r];
                 if (pair) {
                     *(v2f*)&dst[at] = acc[r];
                     if (DOG) *(v2f*)&dog[at] = d;
@@ -1127,6 +1149,7 @@ void build_ori_bins(OriBins* out)
 struct mif_sift {
     int device = 0, W = 0, H = 0, C = 1, cap = 0, batch = 1;
     bool up = false;                       // first octave at twice the input size
+    float* zero_row = nullptr;             // widest octave row of zeros: the blur's padding rows
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_dep = nullptr;
     OctaveBuf oct[kOctaves];
@@ -1152,26 +1175,28 @@ namespace {
 
 template <int FR>
 void launch_blur_fr(const float* src, size_t src_stride, float* dst, float* dog, size_t pyr_stride, size_t dog_stride,
-                    int w, int h, int nframes, const Taps& t, hipStream_t st)
+                    int w, int h, int nframes, const Taps& t, const float* zero_row, hipStream_t st)
 {
-    dim3 grid((w + kBlurTile - 1) / kBlurTile, (h + kBlurTile - 1) / kBlurTile, nframes);
+    const int tiles_x = (w + kBlurTile - 1) / kBlurTile, tiles_y = (h + kBlurTile - 1) / kBlurTile;
+    const int ntiles = tiles_x * tiles_y * nframes;
+    const int blocks = 8 * ((ntiles + 7) / 8);             // one equal share of the tiles per XCD
     if (dog)
-        hipLaunchKernelGGL((k_blur_level<FR, true>), grid, dim3(256), 0, st, src, src_stride, dst, dog, pyr_stride,
-                           dog_stride, w, h, t);
+        hipLaunchKernelGGL((k_blur_level<FR, true>), dim3(blocks), dim3(256), 0, st, src, src_stride, dst, dog,
+                           pyr_stride, dog_stride, w, h, t, tiles_x, tiles_y, ntiles, zero_row);
     else
-        hipLaunchKernelGGL((k_blur_level<FR, false>), grid, dim3(256), 0, st, src, src_stride, dst, dog, pyr_stride,
-                           dog_stride, w, h, t);
+        hipLaunchKernelGGL((k_blur_level<FR, false>), dim3(blocks), dim3(256), 0, st, src, src_stride, dst, dog,
+                           pyr_stride, dog_stride, w, h, t, tiles_x, tiles_y, ntiles, zero_row);
 }
 
 int launch_blur(int fr, const float* src, size_t src_stride, float* dst, float* dog, size_t pyr_stride,
-                size_t dog_stride, int w, int h, int nframes, const Taps& t, hipStream_t st)
+                size_t dog_stride, int w, int h, int nframes, const Taps& t, const float* zero_row, hipStream_t st)
 {
     switch (fr) {
-    case 5: launch_blur_fr<5>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, st); break;
-    case 6: launch_blur_fr<6>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, st); break;
-    case 7: launch_blur_fr<7>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, st); break;
-    case 9: launch_blur_fr<9>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, st); break;
-    case 11: launch_blur_fr<11>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, st); break;
+    case 5: launch_blur_fr<5>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, zero_row, st); break;
+    case 6: launch_blur_fr<6>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, zero_row, st); break;
+    case 7: launch_blur_fr<7>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, zero_row, st); break;
+    case 9: launch_blur_fr<9>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, zero_row, st); break;
+    case 11: launch_blur_fr<11>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, zero_row, st); break;
     default:
         mif::set_error("no blur kernel for tap radius %d", fr);
         return MIF_ERR_UNSUPPORTED;
@@ -1229,7 +1254,7 @@ int enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes)
             float* dst = O.pyr + (size_t)l * items;
             float* dog = (l == 0) ? nullptr : O.dog + (size_t)(l - 1) * items;
             const int rc = launch_blur(s->fr[l], src, src_stride, dst, dog, pyr_stride, dog_stride, O.w, O.h, nf,
-                                       s->ktaps[l], st);
+                                       s->ktaps[l], s->zero_row, st);
             if (rc != MIF_OK) return rc;
         }
         if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][2], st));
@@ -1303,7 +1328,7 @@ void free_all(mif_sift* s)
         (void)hipFree(O.mask); (void)hipFree(O.rowcnt); (void)hipFree(O.rowoff);
     }
     (void)hipFree(s->d_pixels); (void)hipFree(s->kp); (void)hipFree(s->orient);
-    (void)hipFree(s->desc); (void)hipFree(s->counts);
+    (void)hipFree(s->desc); (void)hipFree(s->counts); (void)hipFree(s->zero_row);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -1351,6 +1376,8 @@ int create_impl(mif_sift* s)
     }
     if (s->cap < 1) s->cap = 1;            // keep every result buffer addressable
     const size_t cap = (size_t)s->cap;
+    MIF_HIP(hipMalloc(&s->zero_row, (size_t)s->oct[0].w * sizeof(float)));
+    MIF_HIP(hipMemset(s->zero_row, 0, (size_t)s->oct[0].w * sizeof(float)));
     MIF_HIP(hipMalloc(&s->d_pixels, (size_t)s->W * s->H * s->C));
     MIF_HIP(hipMalloc(&s->kp, B * cap * sizeof(float4)));
     MIF_HIP(hipMalloc(&s->orient, B * cap * sizeof(float)));
