@@ -15,6 +15,7 @@
 // operations spelled fmaf, transcendental functions from mif_math.h), so
 // keypoint counts, positions, orientations and descriptors are reproducible bit
 // for bit and independent of scheduling.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <cmath>
@@ -34,6 +35,12 @@ constexpr int kOriLanes = 16;      // _SIFT_ORIENT_GPU_BLOCKSIZE, sift.cpp:27
 constexpr int kMaxTaps = 24;
 constexpr float kResampleRatio = 2.0f;   // _resample_ratio_x / _y, sift.cpp:812-813
 constexpr int kBlurTile = 64;      // output tile edge of the blur kernel
+// Blocks per frame of the descriptor and orientation kernels (their grids' x extent). The
+// lists' capacity is about ten times what a frame yields, so a grid of one block per slot would
+// mostly start blocks that exit at once; a block walks the list with the grid's stride instead.
+// Few blocks per frame balance badly (keypoints differ in cost): both values were measured.
+constexpr int kDescBlocks = 1024;
+constexpr int kOriBlocks = 128;
 
 // Kernel constants as the reference's kernels see them: the host prints them
 // into -D options with 6 significant digits and OpenCL C parses them as double
@@ -64,6 +71,19 @@ struct OriBins {
 enum { CNT_OCT0 = 0, CNT_TOTAL = 3, CNT_RAW0 = 4, CNT_STATUS = 7, CNT_WORDS = 8 };
 
 // ---------------------------------------------------------------- base image
+
+// Consecutive blocks of a launch go to consecutive XCDs (8 of them, each with its own L2).
+// The bandwidth kernels below run on a 1-D grid of 8 * ceil(nitems / 8) blocks and renumber
+// it so that every XCD owns ONE contiguous range of the work items (tiles or strips in
+// frame-major raster order): neighbours, which share halo rows and columns, then meet in the
+// same L2 instead of fetching the halo from memory once per XCD. Returns -1 for a surplus block.
+__device__ __forceinline__ int xcd_contiguous_item(int nitems)
+{
+    const int per_xcd = (nitems + 7) >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int t = xcd * per_xcd + (int)(blockIdx.x >> 3);
+    return (t < min((xcd + 1) * per_xcd, nitems)) ? t : -1;
+}
 
 // sift.cpp:901-913 copy_pixels_1ch8_to_1ch32 (a host loop in the reference)
 // All kernels below take the frame of a batch from the last grid dimension and
@@ -215,10 +235,8 @@ __global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ sr
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // block -> tile
-    const int per_xcd = (ntiles + 7) >> 3;
-    const int xcd = blockIdx.x & 7;
-    const int t = xcd * per_xcd + (int)(blockIdx.x >> 3);
-    if (t >= min((xcd + 1) * per_xcd, ntiles)) return;       // uniform over the block
+    const int t = xcd_contiguous_item(ntiles);
+    if (t < 0) return;                           // uniform over the block
     const int tiles_xy = tiles_x * tiles_y;
     const int z = t / tiles_xy;
     const int rem = t - z * tiles_xy;
@@ -495,15 +513,19 @@ constexpr int kDetQueue = 4096;
 
 __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ dog, size_t dog_stride,
                                                 unsigned long long* __restrict__ mask, int* __restrict__ rowcnt,
-                                                int w, int h, int words, int o)
+                                                int w, int h, int words, int o, int nbx, int nby, int nblocks)
 {
     __shared__ int s_queue[kDetQueue];
     __shared__ int s_ncand;
-    const int f = blockIdx.z;
+    const int item = xcd_contiguous_item(nblocks);
+    if (item < 0) return;                        // uniform over the block
+    const int f = item / (nbx * nby);
+    const int by = (item - f * nbx * nby) / nbx;
+    const int bx = item - (f * nby + by) * nbx;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int x = (blockIdx.x * 4 + wave) * kDetCols + lane - 1;
-    const int y0 = blockIdx.y * kDetRows;
+    const int x = (bx * 4 + wave) * kDetCols + lane - 1;
+    const int y0 = by * kDetRows;
     const size_t items = (size_t)w * h;
     dog += (size_t)f * dog_stride;
     if (threadIdx.x == 0) s_ncand = 0;
@@ -561,7 +583,7 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ dog, s
                 const int e = s_queue[q];
                 const int s = e >> 28;
                 const int y = y0 + ((e >> 16) & 0xfff);
-                const int cx = (e & 0xffff) - 1 + blockIdx.x * 4 * kDetCols;
+                const int cx = (e & 0xffff) - 1 + bx * 4 * kDetCols;
                 float4 kp;
                 if (refine_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o, cx, y,
                                  &kp)) {
@@ -612,7 +634,7 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ dog, s
                                    (cur < minP[s - 1] && cur < minC[s - 1] && cur < min9[s - 1]));
                 if (cand)
                     s_queue[atomicAdd(&s_ncand, 1)] =
-                        (s << 28) | ((y - y0) << 16) | (x - (int)blockIdx.x * 4 * kDetCols + 1);
+                        (s << 28) | ((y - y0) << 16) | (x - bx * 4 * kDetCols + 1);
             }
         }
     }
@@ -792,110 +814,125 @@ __global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ k
     const int grp = threadIdx.x >> 4;
     const int lid = threadIdx.x & 15;
     const int n = counts[CNT_OCT0 + o];
-    if ((int)blockIdx.x * 4 >= n) return;               // uniform over the block
-    const int g = blockIdx.x * 4 + grp;
-    const bool active = g < n;
-    const int gi = octave_base(counts, o) + g;
+    const int first = octave_base(counts, o);
     float* hist = s_hist[grp][lid];
-    for (int i = 0; i < kOriBins; i++) hist[i] = 0.0f;
-    __syncthreads();                                    // s_thr is complete
+    // a block (one wave) takes four keypoints at a time and walks the frame's list with
+    // the grid's stride; the list capacity is far larger than the list
+    for (int q = blockIdx.x; q * 4 < n; q += gridDim.x) {      // uniform over the block
+        const int g = q * 4 + grp;
+        const bool active = g < n;
+        const int gi = first + g;
+        for (int i = 0; i < kOriBins; i++) hist[i] = 0.0f;
+        __syncthreads();                                    // s_thr is complete; the last round's reads are done
 
-    if (active) {
-        const float4 f4 = kp[gi];
-        const float exp_denom = (float)((double)f4.z * K_ORI_SIG_FCTR);
-        const int rad = (int)mif_round(K_ORI_RADIUS * (double)f4.z);
-        const float exp_factor = -0.5f / (exp_denom * exp_denom);
-        const int sq_thres = rad * rad;
-        // the reference offsets the pyramid by (int)(w*h*level) floats (sift.cpp:459); the
-        // gradient planes are stored from level 1 on
-        const int offset_py = (int)((float)(w * h) * f4.w) - w * h;
-        const float p2o = mif_pow2i(o);
-        const int x = (int)(f4.x / p2o);
-        const int y = (int)(f4.y / p2o);
-        const int xmin = max(1, x - rad), ymin = max(1, y - rad);
-        const int xmax = min(w - 2, x + rad), ymax = min(h - 2, y + rad);
-        const int wx = xmax - xmin + 1, hy = ymax - ymin + 1;
-        const int loops = wx * hy;
-        const float2* img = grad + offset_py;
-        // window pixel i = (i / wx + ymin, i % wx + xmin), i = lid, lid + 16, ...
-        // the window is clipped to [1, w-2] x [1, h-2], so every window pixel can be
-        // gathered; the next pixel's load is issued before the current one is processed
-        int yn = lid / wx + ymin;
-        int xn = lid % wx + xmin;
-        float2 gnext = (lid < loops) ? img[yn * w + xn] : make_float2(0.0f, 0.0f);
-        for (int i = lid; i < loops; i += kOriLanes) {
-            const int xx = xn, yy = yn;
-            const float2 g2 = gnext;
-            xn += kOriLanes;
-            while (xn > xmax) { xn -= wx; yn++; }
-            if (i + kOriLanes < loops) gnext = img[yn * w + xn];
-            if (xx > 0 && xx < w - 1 && yy > 0 && yy < h - 1) {
-                const float ddx = (float)(xx - x), ddy = (float)(yy - y);
-                const int sq_dist = (int)(ddx * ddx + ddy * ddy);
-                if (sq_dist <= sq_thres) {
-                    const float grad = mif_fabsf(g2.x);
-                    const float theta = g2.y;
-                    // bin = round(36 (theta + pi) / (2 pi)) in double (sift.cpp:493), a monotone
-                    // step function of theta: a float estimate that is off by at most one,
-                    // corrected against the exact thresholds
-                    int bin = min(max((int)__builtin_fmaf(theta, 5.72957795130823f, 18.5f), 0), kOriBins);
-                    bin += (theta >= s_thr[bin + 1]) ? 1 : 0;
-                    bin -= (theta < s_thr[bin]) ? 1 : 0;
-                    bin = (bin < kOriBins) ? bin : 0;
-                    // sq_dist <= rad^2 with rad = round(4.5 sigma) and exp_factor = -0.5 / (1.5 sigma)^2:
-                    // the argument stays above -6
-                    hist[bin] += grad * mif_expf_bounded((float)sq_dist * exp_factor);
+        if (active) {
+            const float4 f4 = kp[gi];
+            const float exp_denom = (float)((double)f4.z * K_ORI_SIG_FCTR);
+            const int rad = (int)mif_round(K_ORI_RADIUS * (double)f4.z);
+            const float exp_factor = -0.5f / (exp_denom * exp_denom);
+            const int sq_thres = rad * rad;
+            // the reference offsets the pyramid by (int)(w*h*level) floats (sift.cpp:459); the
+            // gradient planes are stored from level 1 on
+            const int offset_py = (int)((float)(w * h) * f4.w) - w * h;
+            const float p2o = mif_pow2i(o);
+            const int x = (int)(f4.x / p2o);
+            const int y = (int)(f4.y / p2o);
+            const int xmin = max(1, x - rad), ymin = max(1, y - rad);
+            const int xmax = min(w - 2, x + rad), ymax = min(h - 2, y + rad);
+            const int wx = xmax - xmin + 1, hy = ymax - ymin + 1;
+            const int loops = wx * hy;
+            const float2* img = grad + offset_py;
+            // window pixel i = (i / wx + ymin, i % wx + xmin), i = lid, lid + 16, ...
+            // the window is clipped to [1, w-2] x [1, h-2], so every window pixel can be
+            // gathered; the next pixel's load is issued before the current one is processed
+            int yn = lid / wx + ymin;
+            int xn = lid % wx + xmin;
+            float2 gnext = (lid < loops) ? img[yn * w + xn] : make_float2(0.0f, 0.0f);
+            for (int i = lid; i < loops; i += kOriLanes) {
+                const int xx = xn, yy = yn;
+                const float2 g2 = gnext;
+                xn += kOriLanes;
+                while (xn > xmax) { xn -= wx; yn++; }
+                if (i + kOriLanes < loops) gnext = img[yn * w + xn];
+                if (xx > 0 && xx < w - 1 && yy > 0 && yy < h - 1) {
+                    const float ddx = (float)(xx - x), ddy = (float)(yy - y);
+                    const int sq_dist = (int)(ddx * ddx + ddy * ddy);
+                    if (sq_dist <= sq_thres) {
+                        const float grad = mif_fabsf(g2.x);
+                        const float theta = g2.y;
+                        // bin = round(36 (theta + pi) / (2 pi)) in double (sift.cpp:493), a monotone
+                        // step function of theta: a float estimate that is off by at most one,
+                        // corrected against the exact thresholds
+                        int bin = min(max((int)__builtin_fmaf(theta, 5.72957795130823f, 18.5f), 0), kOriBins);
+                        bin += (theta >= s_thr[bin + 1]) ? 1 : 0;
+                        bin -= (theta < s_thr[bin]) ? 1 : 0;
+                        bin = (bin < kOriBins) ? bin : 0;
+                        // sq_dist <= rad^2 with rad = round(4.5 sigma) and exp_factor = -0.5 / (1.5 sigma)^2:
+                        // the argument stays above -6
+                        hist[bin] += grad * mif_expf_bounded((float)sq_dist * exp_factor);
+                    }
                 }
             }
         }
-    }
-    __syncthreads();
-    // tree reduction of the 16 private histograms, association as sift.cpp:509-522
-    for (int i = lid; i < kOriBins; i += kOriLanes) {
-        float v[kOriLanes];
+        __syncthreads();
+        // tree reduction of the 16 private histograms, association as sift.cpp:509-522
+        for (int i = lid; i < kOriBins; i += kOriLanes) {
+            float v[kOriLanes];
 #pragma unroll
-        for (int l = 0; l < kOriLanes; l++) v[l] = s_hist[grp][l][i];
+            for (int l = 0; l < kOriLanes; l++) v[l] = s_hist[grp][l][i];
 #pragma unroll
-        for (int l = 0; l < 8; l++) v[l] += v[l + 8];
+            for (int l = 0; l < 8; l++) v[l] += v[l + 8];
 #pragma unroll
-        for (int l = 0; l < 4; l++) v[l] += v[l + 4];
+            for (int l = 0; l < 4; l++) v[l] += v[l + 4];
 #pragma unroll
-        for (int l = 0; l < 2; l++) v[l] += v[l + 2];
-        v[0] += v[1];
-        s_hist[grp][0][i] = v[0];     // only this lane touches column i
-    }
-    __syncthreads();
-    if (!active || lid != 0) return;
+            for (int l = 0; l < 2; l++) v[l] += v[l + 2];
+            v[0] += v[1];
+            s_hist[grp][0][i] = v[0];     // only this lane touches column i
+        }
+        __syncthreads();
 
-    float* hs = s_hist[grp][0];
-    for (int j = 0; j < 2; j++) {       // two [1/4 1/2 1/4] passes in double, sift.cpp:531-543
-        const float h0 = hs[0];
-        float hp = hs[kOriBins - 1];
-        for (int i = 0; i < kOriBins; i++) {
+        // Two [1/4 1/2 1/4] passes in double (sift.cpp:531-543). The reference's single work-item
+        // updates in place but feeds every bin the OLD values of both neighbours, so the bins of a
+        // pass are independent: the 16 lanes share them, rows 0 -> 1 -> 2 of the group's array.
+        for (int j = 0; j < 2; j++) {
+            const float* in = s_hist[grp][j];
+            float* out = s_hist[grp][j + 1];
+            for (int i = lid; i < kOriBins; i += kOriLanes) {
+                const float hp = in[(i == 0) ? (kOriBins - 1) : (i - 1)];
+                const float hc = in[i];
+                const float hn = in[(i + 1 == kOriBins) ? 0 : (i + 1)];
+                out[i] = (float)(0.25 * (double)hp + 0.5 * (double)hc + 0.25 * (double)hn);
+            }
+            __syncthreads();
+        }
+        // The reference scans the bins upwards and keeps the LAST peak that reaches 0.8 of the
+        // maximum (sift.cpp:545-580): every lane tests its bins, the highest bin index wins.
+        const float* hs = s_hist[grp][2];
+        float v = hs[0];
+        for (int i = 1; i < kOriBins; i++)
+            if (hs[i] > v) v = hs[i];
+        v = (float)(K_ORI_PEAK_RATIO * (double)v);
+        int best = -1;
+        float result = -1.0f;               // _ORIENT_INIT_CONST
+        for (int i = lid; i < kOriBins; i += kOriLanes) {
             const float hc = hs[i];
-            const float hn = (i + 1 == kOriBins) ? h0 : hs[i + 1];
-            hs[i] = (float)(0.25 * (double)hp + 0.5 * (double)hc + 0.25 * (double)hn);
-            hp = hc;
+            const float hp = hs[(i == 0) ? (kOriBins - 1) : (i - 1)];
+            const float hn = hs[(i + 1) % kOriBins];
+            if (hc >= v && hc > hn && hc > hp) {
+                float fbin = (float)((double)(float)i +
+                                     ((double)(0.5f * (hp - hn)) / ((double)hp - 2.0 * (double)hc + (double)hn)));
+                fbin = (fbin < 0.0f) ? (fbin + (float)kOriBins)
+                                     : ((fbin >= (float)kOriBins) ? (fbin - (float)kOriBins) : fbin);
+                result = (float)(((K_M_PI2 * (double)fbin) / kOriBins) - K_M_PI);
+                best = i;
+            }
         }
+        // highest qualifying bin of the 16 lanes (xor shuffles stay inside the group of 16)
+        int top = best;
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) top = max(top, __shfl_xor(top, m, 64));
+        if (active && (top < 0 ? lid == 0 : best == top)) orient[gi] = result;
     }
-    float v = hs[0];
-    for (int i = 1; i < kOriBins; i++)
-        if (hs[i] > v) v = hs[i];
-    v = (float)(K_ORI_PEAK_RATIO * (double)v);
-    float result = -1.0f;               // _ORIENT_INIT_CONST
-    for (int i = 0; i < kOriBins; i++) {
-        const float hc = hs[i];
-        const float hp = hs[(i == 0) ? (kOriBins - 1) : (i - 1)];
-        const float hn = hs[(i + 1) % kOriBins];
-        if (hc >= v && hc > hn && hc > hp) {
-            float fbin = (float)((double)(float)i +
-                                 ((double)(0.5f * (hp - hn)) / ((double)hp - 2.0 * (double)hc + (double)hn)));
-            fbin = (fbin < 0.0f) ? (fbin + (float)kOriBins)
-                                 : ((fbin >= (float)kOriBins) ? (fbin - (float)kOriBins) : fbin);
-            result = (float)(((K_M_PI2 * (double)fbin) / kOriBins) - K_M_PI);
-        }
-    }
-    orient[gi] = result;
 }
 
 // ---------------------------------------------------------------- descriptor
@@ -924,13 +961,16 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
     desc += (size_t)f * cap * 128;
     grad += (size_t)f * grad_stride;
     const int n = counts[CNT_OCT0 + o];
-    if ((int)blockIdx.x >= n) return;                  // uniform over the block
-    const int gi = octave_base(counts, o) + blockIdx.x;
+    const int first = octave_base(counts, o);
     const int tid = threadIdx.x;
     const int lid = tid & 7;
     const int bid = tid >> 3;
     const int ix = bid & 3, iy = bid >> 2;
     float* d = s_des[bid][lid];
+    // the grid's x extent is far smaller than the list capacity (most of which stays empty):
+    // a block walks the frame's keypoints with the grid's stride
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {      // uniform over the block
+    const int gi = first + k;
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = 0.0f;
 
@@ -1048,6 +1088,8 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
     __syncthreads();
     const float v1 = (float)K_INT_DESCR_FCTR * (v0 * s_norm);
     desc[(size_t)gi * 128 + tid] = clampf(v1, 0.0f, 255.0f);
+    // the next keypoint's first writes to s_val / s_sq / s_norm come after its first barrier
+    }
 }
 
 // After the last octave, one thread per frame: status = 0, or -1 when an
@@ -1278,9 +1320,12 @@ int enqueue_features(mif_sift* s, int want_desc)
         if (tm) MIF_HIP(hipEventRecord(s->ev_feat[o][0], st));
         MIF_HIP(hipMemsetAsync(O.rowcnt, 0, (size_t)nf * O.rows * sizeof(int), st));
         MIF_HIP(hipMemsetAsync(O.mask, 0, (size_t)nf * O.rows * O.words * sizeof(unsigned long long), st));
-        hipLaunchKernelGGL(k_detect, dim3((O.w + 4 * kDetCols - 1) / (4 * kDetCols), (O.h + kDetRows - 1) / kDetRows, nf),
-                           dim3(256), 0, st,
-                           (const float*)O.dog, dog_stride, O.mask, O.rowcnt, O.w, O.h, O.words, o);
+        {
+            const int nbx = (O.w + 4 * kDetCols - 1) / (4 * kDetCols), nby = (O.h + kDetRows - 1) / kDetRows;
+            const int nblocks = nbx * nby * nf;
+            hipLaunchKernelGGL(k_detect, dim3(8 * ((nblocks + 7) / 8)), dim3(256), 0, st, (const float*)O.dog,
+                               dog_stride, O.mask, O.rowcnt, O.w, O.h, O.words, o, nbx, nby, nblocks);
+        }
         hipLaunchKernelGGL(k_scan_rows, dim3(nf), dim3(1024), 0, st, (const int*)O.rowcnt, O.rowoff, O.rows, O.maxf,
                            o, s->counts);
         if (O.maxf > 0) {
@@ -1293,10 +1338,11 @@ int enqueue_features(mif_sift* s, int want_desc)
                 hipLaunchKernelGGL(k_gradient, dim3((O.w + 255) / 256, (O.h + kGradRows - 1) / kGradRows, kIntervals * nf),
                                    dim3(256), 0, st,
                                    (const float*)O.pyr, pyr_stride, O.grad, grad_stride, O.w, O.h);
-                hipLaunchKernelGGL(k_orientation, dim3((O.maxf + 3) / 4, nf), dim3(64), 0, st, (const float4*)s->kp,
+                hipLaunchKernelGGL(k_orientation, dim3(std::min((O.maxf + 3) / 4, kOriBlocks), nf), dim3(64), 0, st,
+                                   (const float4*)s->kp,
                                    (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap, (const int*)s->counts,
                                    s->orient, s->ori_bins);
-                hipLaunchKernelGGL(k_descriptor, dim3(O.maxf, nf), dim3(128), 0, st, (const float4*)s->kp,
+                hipLaunchKernelGGL(k_descriptor, dim3(std::min(O.maxf, kDescBlocks), nf), dim3(128), 0, st, (const float4*)s->kp,
                                    (const float*)s->orient, (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap,
                                    (const int*)s->counts, s->desc);
             }
