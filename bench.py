@@ -64,8 +64,14 @@ def make_frames(width, height, batch, rank, channels=3):
     workers = min(8, batch)
     if workers > 1:
         import multiprocessing as mp
-        with mp.get_context("fork").Pool(workers) as pool:
+        # close + join, not the context manager: its exit terminates the workers with SIGTERM,
+        # which a profiler's signal handler inherited by the workers may turn into a hang
+        pool = mp.get_context("fork").Pool(workers)
+        try:
             frames = pool.map(_frame, jobs)
+        finally:
+            pool.close()
+            pool.join()
     else:
         frames = [_frame(j) for j in jobs]
     return np.stack(frames)
@@ -253,7 +259,8 @@ def main():
 
     # stage times of the last two batches of the timed region (one per handle), measured with HIP events on
     # the handles' own streams; blur_level is the dominant bandwidth kernel (6 launches per octave)
-    stage = np.mean([h.stage_times() for h in pipe.h], axis=0)            # ms [octave][stage]
+    timed = [pipe.h[(pipe.last() - i) % len(pipe.h)] for i in range(min(len(pipe.h), args.steps))]
+    stage = np.mean([h.stage_times() for h in timed], axis=0)             # ms [octave][stage]
     px = [h_ * w_ for (w_, h_, _) in (pipe.h[0].octave_info(o) for o in range(3))]
     blur_ms = float(stage[:, 1].sum())
     alg_bytes = ALG_BYTES_PER_PX_OCTAVE * sum(px) * args.batch

@@ -4,14 +4,19 @@ memory-side bytes per kernel, and the scale-space (k_blur_level) total per frame
 
 usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv frames_per_batch out.json
 
-FETCH_SIZE / WRITE_SIZE are reported in KiB-like units of 1024 bytes by rocprofv3. The blur kernel reads
-with 4-byte-per-lane loads, for which FETCH_SIZE was checked against known byte counts (k_gray, k_detect)
-and needs no factor; its stores are 8 bytes per lane.
+FETCH_SIZE / WRITE_SIZE are reported in units of 1024 bytes by rocprofv3. On gfx950 FETCH_SIZE tallies
+the 128-byte requests of coalesced reads at 64 bytes, i.e. reports half of the bytes (checked here on
+kernels with known byte counts: k_gray_bgr_x4 reads 3 B/px, k_decimate touches every other row; both
+come out at 0.50 of their bytes), so it is doubled; WRITE_SIZE is exact for these stores. The JSON keeps
+the raw fetch figure next to the corrected one.
 """
 import collections
 import csv
 import json
 import sys
+
+
+FETCH_FACTOR = 2.0        # gfx950: FETCH_SIZE counts a 128-byte request as 64 bytes
 
 
 def per_kernel(path, counter):
@@ -36,10 +41,11 @@ def main():
         fb, fc = fetch.get(k, (0.0, 0))
         wb, wc = write.get(k, (0.0, 0))
         calls = max(fc, wc)
-        out["kernels"][k] = {"launches": calls, "fetch_bytes_per_launch": fb / max(fc, 1),
+        out["kernels"][k] = {"launches": calls, "fetch_bytes_per_launch": FETCH_FACTOR * fb / max(fc, 1),
+                             "fetch_size_raw_per_launch": fb / max(fc, 1),
                              "write_bytes_per_launch": wb / max(wc, 1)}
         if k.startswith("k_blur_level"):
-            blur_bytes += fb / max(fc, 1) * calls + wb / max(wc, 1) * calls
+            blur_bytes += FETCH_FACTOR * fb / max(fc, 1) * calls + wb / max(wc, 1) * calls
             blur_launches += calls
     batches = blur_launches / 18.0                       # 18 blur launches per batch (3 octaves x 6 levels)
     out["blur_bytes_per_frame"] = blur_bytes / batches / frames
