@@ -527,8 +527,6 @@ int pick_split(int nq, int nd, int npairs, bool device_counts)
     // an eighth of them (blocks beyond the real counts exit at once).
     if (const char* e = getenv("MIF_MATCH_SPLIT"))       // tuning override
         return std::max(1, std::min(atoi(e), kMaxSplit));
-    if (const char* e = getenv("MIF_MATCH_SPLIT"))       // tuning override
-        return std::max(1, std::min(atoi(e), kMaxSplit));
     if (device_counts) {
         nq = std::max(1, nq / 8);
         nd = std::max(1, nd / 8);

@@ -39,8 +39,9 @@ constexpr int kBlurTile = 64;      // output tile edge of the blur kernel
 // lists' capacity is about ten times what a frame yields, so a grid of one block per slot would
 // mostly start blocks that exit at once; a block walks the list with the grid's stride instead.
 // Few blocks per frame balance badly (keypoints differ in cost): both values were measured.
-constexpr int kDescBlocks = 1024;
-constexpr int kOriBlocks = 128;
+// Small batches get more blocks per frame, so that the launch still fills the GPU.
+constexpr int kDescBlocks = 1024, kDescBlocksTotal = 65536;
+constexpr int kOriBlocks = 128, kOriBlocksTotal = 32768;
 
 // Kernel constants as the reference's kernels see them: the host prints them
 // into -D options with 6 significant digits and OpenCL C parses them as double
@@ -93,6 +94,21 @@ __global__ void k_gray_u8(const uint8_t* __restrict__ in, float* __restrict__ ou
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t f = blockIdx.z;
     if (i < n) out[f * n + i] = (float)in[f * n + i] / 255.0f;
+}
+
+// the same, four pixels per thread (one 32-bit word in, one float4 out); n % 4 == 0
+__global__ void k_gray_u8_x4(const uint8_t* __restrict__ in, float* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // group of four pixels
+    const size_t f = blockIdx.z;
+    if (i * 4 >= n) return;
+    const uint32_t v = reinterpret_cast<const uint32_t*>(in + f * n)[i];
+    float4 o;
+    o.x = (float)(v & 0xffu) / 255.0f;
+    o.y = (float)((v >> 8) & 0xffu) / 255.0f;
+    o.z = (float)((v >> 16) & 0xffu) / 255.0f;
+    o.w = (float)(v >> 24) / 255.0f;
+    reinterpret_cast<float4*>(out + f * n)[i] = o;
 }
 
 // sift.cpp:55-72 kColor_interleaved_ch
@@ -1280,6 +1296,9 @@ int enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes)
             else if (s->C == 3)
                 hipLaunchKernelGGL(k_gray_bgr, dim3((items + 255) / 256, 1, nf), dim3(256), 0, st,
                                    (const uint8_t*)d_pixels, O.base, items);
+            else if (items % 4 == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 3u) == 0)
+                hipLaunchKernelGGL(k_gray_u8_x4, dim3((items / 4 + 255) / 256, 1, nf), dim3(256), 0, st,
+                                   (const uint8_t*)d_pixels, O.base, items);
             else
                 hipLaunchKernelGGL(k_gray_u8, dim3((items + 255) / 256, 1, nf), dim3(256), 0, st,
                                    (const uint8_t*)d_pixels, O.base, items);
@@ -1338,11 +1357,12 @@ int enqueue_features(mif_sift* s, int want_desc)
                 hipLaunchKernelGGL(k_gradient, dim3((O.w + 255) / 256, (O.h + kGradRows - 1) / kGradRows, kIntervals * nf),
                                    dim3(256), 0, st,
                                    (const float*)O.pyr, pyr_stride, O.grad, grad_stride, O.w, O.h);
-                hipLaunchKernelGGL(k_orientation, dim3(std::min((O.maxf + 3) / 4, kOriBlocks), nf), dim3(64), 0, st,
+                hipLaunchKernelGGL(k_orientation, dim3(std::min((O.maxf + 3) / 4, std::max(kOriBlocks, kOriBlocksTotal / nf)), nf), dim3(64), 0, st,
                                    (const float4*)s->kp,
                                    (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap, (const int*)s->counts,
                                    s->orient, s->ori_bins);
-                hipLaunchKernelGGL(k_descriptor, dim3(std::min(O.maxf, kDescBlocks), nf), dim3(128), 0, st, (const float4*)s->kp,
+                hipLaunchKernelGGL(k_descriptor, dim3(std::min(O.maxf, std::max(kDescBlocks, kDescBlocksTotal / nf)), nf), dim3(128), 0, st,
+                                   (const float4*)s->kp,
                                    (const float*)s->orient, (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap,
                                    (const int*)s->counts, s->desc);
             }
