@@ -34,6 +34,7 @@ constexpr int kOriBins = 36;       // _SIFT_ORI_HIST_BINS, sift.cpp:26
 constexpr int kOriLanes = 16;      // _SIFT_ORIENT_GPU_BLOCKSIZE, sift.cpp:27
 constexpr int kMaxTaps = 24;
 constexpr float kResampleRatio = 2.0f;   // _resample_ratio_x / _y, sift.cpp:812-813
+typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int kBlurTile = 64;      // output tile edge of the blur kernel
 // Blocks per frame of the descriptor and orientation kernels (their grids' x extent). The
 // lists' capacity is about ten times what a frame yields, so a grid of one block per slot would
@@ -220,7 +221,6 @@ __global__ void k_decimate(const float* __restrict__ src, size_t src_stride, flo
 // Tiles (frame-major, then raster order) are cut into 8 contiguous ranges, one
 // per XCD (consecutive blocks go to consecutive XCDs), so that neighbouring
 // tiles, which share halo rows and columns, meet in the same L2.
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int FR, bool DOG>
 __global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ src, size_t src_stride,
@@ -766,10 +766,10 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ dog, siz
 // dy != 0 and theta when dy == 0 (mif_atan2f is odd in y except at y = 0), so
 // both kernels read back exactly the values they would have computed.
 // Border pixels are never sampled (windows are clipped to [1, w-2] x [1, h-2])
-// and are not written. A thread owns one column of four consecutive rows and
-// issues all 14 loads before the first use, which keeps enough bytes in flight
-// per wave to cover the HBM latency. grid (ceil(w/256), ceil(h/4), 3 levels x frames).
-constexpr int kGradRows = 4;
+// and are not written. A thread owns one column of eight consecutive rows and
+// issues all 26 loads before the first use, which keeps enough bytes in flight
+// per wave to cover the HBM latency. grid (ceil(w/256), ceil(h/8), 3 levels x frames).
+constexpr int kGradRows = 8;
 
 __global__ __launch_bounds__(256) void k_gradient(const float* __restrict__ pyr, size_t pyr_stride,
                                                   float2* __restrict__ grad, size_t grad_stride, int w, int h)
@@ -803,7 +803,10 @@ __global__ __launch_bounds__(256) void k_gradient(const float* __restrict__ pyr,
         const float mag = __builtin_sqrtf(dx * dx + dy * dy);
         const float theta = mif_atan2f(dy, dx);
         const uint32_t mb = (mif_float_to_bits(mag) & 0x7fffffffu) | (dy != 0.0f ? 0x80000000u : 0u);
-        out[(size_t)y * w + x] = make_float2(mif_bits_to_float(mb), theta);
+        // streamed past the L2 (nothing reads the planes before the launch ends), which keeps the
+        // rows that neighbouring blocks share resident there
+        const v2f val = (v2f){mif_bits_to_float(mb), theta};
+        __builtin_nontemporal_store(val, (v2f*)&out[(size_t)y * w + x]);
     }
 }
 
