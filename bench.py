@@ -46,6 +46,10 @@ def parse_args():
     ap.add_argument("--channels", type=int, default=3, choices=[1, 3])
     ap.add_argument("--no-match", action="store_true",
                     help="extraction only (the 4K batch configuration: --width 3840 --height 2160 --channels 1)")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="frames start in pinned host memory: every step uploads its batch over PCIe on a copy "
+                         "stream (overlapping the previous batch) and downloads the match summaries; the "
+                         "PCIe-inclusive rate, never the headline value")
     ap.add_argument("--serial", action="store_true",
                     help="run the matcher of a batch after its feature phase instead of beside the next one's")
     return ap.parse_args()
@@ -236,8 +240,32 @@ def main():
     pipe = Pipeline(oda, torch, local_rank, args.width, args.height, args.batch, serial=args.serial,
                     channels=args.channels, match=not args.no_match)
 
+    if args.host_frames:
+        host = torch.from_numpy(frames_np).pin_memory()
+        dev_buf = [torch.empty_like(frames), frames]
+        cstream, dstream = torch.cuda.Stream(device=frames.device), torch.cuda.Stream(device=frames.device)
+        host_summ = [torch.empty((args.batch, 2), dtype=torch.int32).pin_memory() for _ in range(2)]
+
+        def step():
+            k = pipe.step_no
+            hk = pipe.h[k % 2]
+            # buffer k % 2 was last read by the scale spaces of batch k - 2, enqueued on this handle's stream
+            pipe._wait(cstream.cuda_stream, hk.stream())
+            with torch.cuda.stream(cstream):
+                dev_buf[k % 2].copy_(host, non_blocking=True)
+            pipe._wait(hk.stream(), cstream.cuda_stream)
+            pipe.step(dev_buf[k % 2].data_ptr())
+            if k >= 1 and pipe.match and not pipe.serial:
+                # the matcher of batch k - 1 has just been enqueued: its summaries go back to the host
+                pipe._wait(dstream.cuda_stream, pipe.mstream.cuda_stream)
+                with torch.cuda.stream(dstream):
+                    host_summ[(k - 1) % 2].copy_(pipe.summ[(k - 1) % 2], non_blocking=True)
+    else:
+        def step():
+            pipe.step(frames.data_ptr())
+
     for _ in range(args.warmup):
-        pipe.step(frames.data_ptr())
+        step()
     pipe.sync()
     for h in pipe.h:
         h.set_timing(True)
@@ -246,7 +274,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        pipe.step(frames.data_ptr())
+        step()
     pipe.sync()
     torch.cuda.synchronize()
     barrier()
@@ -308,7 +336,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" + (", uploaded from pinned host memory every step" if args.host_frames else ""),
             "config": {"workload": ("SIFT extract + match-vs-previous-frame on a synthetic %dx%d BGR sequence "
                                     "(stand-in for basketball.mp4, BASELINE.json configs[2])" % (args.width, args.height))
                        if (not args.no_match and args.channels == 3) else
