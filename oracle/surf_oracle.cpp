@@ -412,6 +412,9 @@ void* orc_surf_create(int width, int height)
 
 void orc_surf_destroy(void* h) { delete (Surf*)h; }
 
+// the shared elementary function behind getAngle's atan(|Y/X|), for restatements written elsewhere
+float orc_math_atan_pos(float v) { return atan_pos(v); }
+
 // ccl_surf.cpp:687-731 Surf::run + 789-820 ccl_surf::run. Returns the number of
 // interest points (0 where the reference returns an empty vector).
 int orc_surf_run(void* hdl, const uint8_t* pixels, int channels)

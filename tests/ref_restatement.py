@@ -28,6 +28,8 @@ def _m():
         getattr(L, n).restype = C.c_float
     L.orc_math_atan2f.argtypes = [C.c_float, C.c_float]
     L.orc_math_atan2f.restype = C.c_float
+    L.orc_math_atan_pos.argtypes = [C.c_float]
+    L.orc_math_atan_pos.restype = C.c_float
     return L
 
 
@@ -362,3 +364,189 @@ def surf_select_points(layers, max_points=8000):
                         lap = int(m[1][r * mS, c * mS])
                         out.append((x, y, sc, lap))
     return out[:max_points]
+
+
+# ------------------------------------------------------------------ SURF orientation and descriptor
+#
+# getOrientation_kernels.cl:68-316, createDescriptors_kernel.cl:135-275 and
+# normalizeDescriptors_kernel.cl:54-111, one interest point at a time, every operation rounded to
+# float32 where the kernel computes in float. Written from the kernel text, not from
+# oracle/surf_oracle.cpp. Conventions this build fixes (the reference leaves them open): the 109
+# samples of Step1 are ordered by work-item id instead of by atom_add arrival; dot(v, v) is summed
+# left to right; exp / sin / cos / atan are the build's shared elementary functions.
+
+SURF_PI = f32(3.141592654)                   # "#define pi 3.141592654f" (getOrientation_kernels.cl:57)
+SURF_ID = [6, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5, 6]            # ccl_surf.cpp:753
+SURF_GAUSS25 = [f32(v) for v in (             # ccl_surf.cpp:755-762
+    0.02350693969273, 0.01849121369071, 0.01239503121241, 0.00708015417522, 0.00344628101733, 0.00142945847484, 0.00050524879060,
+    0.02169964028389, 0.01706954162243, 0.01144205592615, 0.00653580605408, 0.00318131834134, 0.00131955648461, 0.00046640341759,
+    0.01706954162243, 0.01342737701584, 0.00900063997939, 0.00514124713667, 0.00250251364222, 0.00103799989504, 0.00036688592278,
+    0.01144205592615, 0.00900063997939, 0.00603330940534, 0.00344628101733, 0.00167748505986, 0.00069579213743, 0.00024593098864,
+    0.00653580605408, 0.00514124713667, 0.00344628101733, 0.00196854695367, 0.00095819467066, 0.00039744277546, 0.00014047800980,
+    0.00318131834134, 0.00250251364222, 0.00167748505986, 0.00095819467066, 0.00046640341759, 0.00019345616757, 0.00006837798818,
+    0.00131955648461, 0.00103799989504, 0.00069579213743, 0.00039744277546, 0.00019345616757, 0.00008024231247, 0.00002836202103)]
+SURF_MJ = [-12, -7, -2, 3] * 4                                # createDescriptors_kernel.cl:207-211
+SURF_MI = [-12] * 4 + [-7] * 4 + [-2] * 4 + [3] * 4           # createDescriptors_kernel.cl:213-217
+
+
+def _cl_round(v):
+    """OpenCL round() of a float32: half away from zero, result float32."""
+    v = float(v)
+    return f32(math.floor(v + 0.5) if v >= 0 else -math.floor(-v + 0.5))
+
+
+def _cdiv(a, b):
+    """C integer division (truncation toward zero)."""
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b >= 0) else -q
+
+
+class _SurfImage:
+    def __init__(self, integral):
+        self.h, self.w = integral.shape
+        self.d = np.ascontiguousarray(integral, np.float32).reshape(-1)
+
+    def box(self, row, col, rows, cols):
+        """BoxIntegral, the buffer variant (getOrientation_kernels.cl:73-108)."""
+        A = B = Cc = D = f32(0.0)
+        r1 = min(row, self.h) - 1
+        c1 = min(col, self.w) - 1
+        r2 = min(row + rows, self.h) - 1
+        c2 = min(col + cols, self.w) - 1
+        if r1 >= 0 and c1 >= 0:
+            A = self.d[r1 * self.w + c1]
+        if r1 >= 0 and c2 >= 0:
+            B = self.d[r1 * self.w + c2]
+        if r2 >= 0 and c1 >= 0:
+            Cc = self.d[r2 * self.w + c1]
+        if r2 >= 0 and c2 >= 0:
+            D = self.d[r2 * self.w + c2]
+        return max(f32(0.0), f32(f32(f32(A - B) - Cc) + D))
+
+    def haar_x(self, row, column, s):
+        return f32(self.box(row - _cdiv(s, 2), column, s, _cdiv(s, 2)) -
+                   self.box(row - _cdiv(s, 2), column - _cdiv(s, 2), s, _cdiv(s, 2)))
+
+    def haar_y(self, row, column, s):
+        return f32(self.box(row, column - _cdiv(s, 2), _cdiv(s, 2), s) -
+                   self.box(row - _cdiv(s, 2), column - _cdiv(s, 2), _cdiv(s, 2), s))
+
+
+def _surf_angle(X, Y):
+    """getAngle (getOrientation_kernels.cl:138-153)."""
+    L = _m()
+    X, Y = f32(X), f32(Y)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if X >= 0 and Y >= 0:
+            return f32(L.orc_math_atan_pos(f32(Y / X)))
+        if X < 0 and Y >= 0:
+            return f32(SURF_PI - f32(L.orc_math_atan_pos(f32(f32(-Y) / X))))
+        if X < 0 and Y < 0:
+            return f32(SURF_PI + f32(L.orc_math_atan_pos(f32(Y / X))))
+        if X >= 0 and Y < 0:
+            return f32(f32(f32(2) * SURF_PI) - f32(L.orc_math_atan_pos(f32(f32(-Y) / X))))
+    return f32(0)
+
+
+def _surf_gaussian(x, y, sig):
+    """gaussian (getOrientation_kernels.cl:68-71): (1/(2 pi sig sig)) * exp(-(x x + y y)/(2 sig sig))."""
+    L = _m()
+    x, y, sig = f32(x), f32(y), f32(sig)
+    norm = f32(f32(1.0) / f32(f32(f32(f32(2.0) * SURF_PI) * sig) * sig))
+    arg = f32(f32(-f32(f32(x * x) + f32(y * y))) / f32(f32(f32(2.0) * sig) * sig))
+    return f32(norm * f32(L.orc_math_expf(arg)))
+
+
+def surf_orientation(integral, x, y, scale):
+    """getOrientationStep1 + Step2 for one interest point -> float32 orientation."""
+    img = _SurfImage(integral)
+    s = int(_cl_round(scale))
+    r = int(_cl_round(y))
+    c = int(_cl_round(x))
+    res = []
+    for local_id in range(169):
+        i = local_id // 13 - 6
+        j = local_id % 13 - 6
+        if i * i + j * j < 36:
+            gauss = SURF_GAUSS25[7 * SURF_ID[i + 6] + SURF_ID[j + 6]]
+            rx = f32(gauss * img.haar_x(r + j * s, c + i * s, 4 * s))
+            ry = f32(gauss * img.haar_y(r + j * s, c + i * s, 4 * s))
+            res.append((rx, ry, _surf_angle(rx, ry)))
+    assert len(res) == 109
+    sums = []
+    two_pi = f32(f32(2) * SURF_PI)
+    for tid in range(42):
+        ang1 = f32(f32(0.15) * f32(tid))
+        third = f32(SURF_PI / f32(3.0))
+        ang2 = f32(ang1 - f32(f32(f32(5.0) * SURF_PI) / f32(3.0))) if f32(ang1 + third) > two_pi else f32(ang1 + third)
+        sx = sy = f32(0.0)
+        for rx, ry, ang in res:
+            if tid <= 34:
+                check = 1 if (ang1 < ang and ang < ang2) else 0
+            else:
+                check = 1 if ((ang > 0 and ang < ang2) or (ang > ang1 and ang < two_pi)) else 0
+            sx = f32(sx + f32(rx * f32(check)))
+            sy = f32(sy + f32(ry * f32(check)))
+        sums.append((sx, sy))
+
+    def mag(v):
+        return f32(f32(v[0] * v[0]) + f32(v[1] * v[1]))
+
+    offset = 32
+    while offset > 0:
+        for tid in range(42):                      # all work-items of a step read before the barrier
+            if tid < offset and tid + offset < 42 and mag(sums[tid]) < mag(sums[tid + offset]):
+                sums[tid] = sums[tid + offset]
+        offset >>= 1
+    return _surf_angle(sums[0][0], sums[0][1])
+
+
+def surf_descriptor(integral, x, y, scale, orient):
+    """createDescriptors + normalizeDescriptors for one interest point -> 64 float32."""
+    L = _m()
+    img = _SurfImage(integral)
+    px = _cl_round(x)
+    py = _cl_round(y)
+    orient = f32(orient)
+    co = f32(L.orc_math_cosf(orient))
+    si = f32(L.orc_math_sinf(orient))
+    th = f32(scale)
+    desc = np.zeros((16, 4), np.float32)
+    lengths = []
+    for b in range(16):
+        cx = f32(f32(0.5) + f32(b // 4))
+        cy = f32(f32(0.5) + f32(b % 4))
+        j, i = SURF_MJ[b], SURF_MI[b]
+        ix, jx = f32(i + 5), f32(j + 5)
+        xs = _cl_round(f32(px + f32(f32(f32(f32(-jx) * th) * si) + f32(f32(ix * th) * co))))
+        ys = _cl_round(f32(py + f32(f32(f32(jx * th) * co) + f32(f32(ix * th) * si))))
+        d = np.zeros((81, 4), np.float32)
+        for tha in range(81):
+            k = i + tha // 9
+            l = j + tha % 9
+            sample_x = int(_cl_round(f32(px + f32(f32(f32(f32(-l) * th) * si) + f32(f32(f32(k) * th) * co)))))
+            sample_y = int(_cl_round(f32(py + f32(f32(f32(f32(l) * th) * co) + f32(f32(f32(k) * th) * si)))))
+            g1 = _surf_gaussian(f32(xs - f32(sample_x)), f32(ys - f32(sample_y)), f32(f32(2.5) * th))
+            hs = int(f32(f32(2) * _cl_round(th)))
+            rx = img.haar_x(sample_y, sample_x, hs)
+            ry = img.haar_y(sample_y, sample_x, hs)
+            rrx = f32(g1 * f32(f32(f32(-rx) * si) + f32(ry * co)))
+            rry = f32(g1 * f32(f32(rx * co) + f32(ry * si)))
+            d[tha] = (rrx, rry, abs(rrx), abs(rry))
+        # sumDesc: items 64..80 fold onto 0..16, then strides 32, 16, ..., 1
+        d[:81 - 64] = d[:81 - 64] + d[64:81]
+        stride = 32
+        while stride > 0:
+            d[:stride] = d[:stride] + d[stride:2 * stride]
+            stride >>= 1
+        g2 = _surf_gaussian(f32(cx - f32(2.0)), f32(cy - f32(2.0)), f32(1.5))
+        v = d[0] * g2
+        desc[b] = v
+        lengths.append(f32(f32(f32(f32(v[0] * v[0]) + f32(v[1] * v[1])) + f32(v[2] * v[2])) + f32(v[3] * v[3])))
+    n = 8
+    while n > 0:
+        for tid in range(n):
+            lengths[tid] = f32(lengths[tid] + lengths[tid + n])
+        n >>= 1
+    inv = f32(f32(1.0) / np.sqrt(lengths[0]))
+    return (desc.reshape(64) * inv).astype(np.float32)

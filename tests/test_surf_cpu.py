@@ -121,3 +121,26 @@ def test_point_selection_against_second_restatement(name):
         assert np.float32(y).view(np.uint32) == row[1].view(np.uint32)
         assert np.float32(sc).view(np.uint32) == row[2].view(np.uint32)
         assert lap == int(row[4])
+
+
+@pytest.mark.parametrize("name", ["box", "scene"])
+def test_orientation_and_descriptor_against_second_restatement(name):
+    """Orientation and the 64 descriptor values of a spread of interest points against the separate
+    Python restatement of getOrientationStep1/2, createDescriptors and normalizeDescriptors
+    (tests/ref_restatement.py), bit for bit. The restatement gets the oracle's integral image and point
+    positions (both pinned by the tests above) and, for the descriptor, the oracle's orientation."""
+    import ref_restatement as ref
+    img = orc.read_pnm(os.path.join(orc.GOLDEN, name + ".pgm"))
+    h, w = img.shape
+    S = orc.SurfOracle(w, h)
+    S.run(img)
+    integral = S.integral()
+    pts = S.points()
+    assert len(pts) > 50
+    picks = sorted(set(np.linspace(0, len(pts) - 1, 12).astype(int).tolist()))
+    for i in picks:
+        x, y, scale, ori = pts[i, 0], pts[i, 1], pts[i, 2], pts[i, 3]
+        want_ori = ref.surf_orientation(integral, x, y, scale)
+        assert np.float32(want_ori).view(np.uint32) == ori.view(np.uint32), (i, want_ori, ori)
+        want_desc = ref.surf_descriptor(integral, x, y, scale, ori)
+        assert np.array_equal(want_desc.view(np.uint32), pts[i, 6:70].view(np.uint32)), i
