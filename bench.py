@@ -243,17 +243,23 @@ def main():
     if args.host_frames:
         host = torch.from_numpy(frames_np).pin_memory()
         dev_buf = [torch.empty_like(frames), frames]
-        cstream, dstream = torch.cuda.Stream(device=frames.device), torch.cuda.Stream(device=frames.device)
+        ncopy = max(1, min(int(os.environ.get("BENCH_COPY_STREAMS", "4")), args.batch))
+        cstreams = [torch.cuda.Stream(device=frames.device) for _ in range(ncopy)]
+        dstream = torch.cuda.Stream(device=frames.device)
+        cuts = [args.batch * i // ncopy for i in range(ncopy + 1)]
         host_summ = [torch.empty((args.batch, 2), dtype=torch.int32).pin_memory() for _ in range(2)]
 
         def step():
             k = pipe.step_no
             hk = pipe.h[k % 2]
             # buffer k % 2 was last read by the scale spaces of batch k - 2, enqueued on this handle's stream
-            pipe._wait(cstream.cuda_stream, hk.stream())
-            with torch.cuda.stream(cstream):
-                dev_buf[k % 2].copy_(host, non_blocking=True)
-            pipe._wait(hk.stream(), cstream.cuda_stream)
+            # (several copy streams: one DMA engine alone does not fill the link)
+            for ci, cs in enumerate(cstreams):
+                pipe._wait(cs.cuda_stream, hk.stream())
+                with torch.cuda.stream(cs):
+                    dev_buf[k % 2][cuts[ci]:cuts[ci + 1]].copy_(host[cuts[ci]:cuts[ci + 1]], non_blocking=True)
+            for cs in cstreams:
+                pipe._wait(hk.stream(), cs.cuda_stream)
             pipe.step(dev_buf[k % 2].data_ptr())
             if k >= 1 and pipe.match and not pipe.serial:
                 # the matcher of batch k - 1 has just been enqueued: its summaries go back to the host
