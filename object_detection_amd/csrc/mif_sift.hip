@@ -812,11 +812,13 @@ __global__ __launch_bounds__(256) void k_gradient(const float* __restrict__ pyr,
 
 // --------------------------------------------------------------- orientation
 
-// sift.cpp:431-582 kOrientation. A block serves four keypoints, 16 lanes each,
-// exactly the reference's work-group of 16: lane l accumulates window pixels
-// l, l+16, ... into its private 36-bin histogram, the 16 histograms are summed
-// with the reference's tree (8, 4, 2, 1) and lane 0 smooths and picks the last
-// qualifying peak.
+// sift.cpp:431-582 kOrientation. A block (one wave) serves four keypoints at a
+// time, 16 lanes each, exactly the reference's work-group of 16: lane l
+// accumulates window pixels l, l+16, ... into its private 36-bin histogram and
+// the 16 histograms are summed with the reference's tree (8, 4, 2, 1). The two
+// smoothing passes and the search for the last qualifying peak, which the
+// reference leaves to work-item 0, are shared by the 16 lanes: every bin of a
+// pass depends on the previous pass only, so the values are the same.
 __global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ kp, const float2* __restrict__ grad,
                                                     size_t grad_stride, int w, int h, int o, int cap,
                                                     const int* __restrict__ counts, float* __restrict__ orient,
