@@ -1,5 +1,7 @@
 """GPU parity of the batched, device-resident path (what bench.py runs): a batch of frames through
 mif_sift_enqueue, then frame-to-previous-frame matching with the SIFT good-match filter on the device."""
+import os
+
 import numpy as np
 import pytest
 
@@ -164,3 +166,30 @@ def test_two_phase_enqueue_snapshot_and_stream_order():
     # the feature phase needs a pending scale space
     with pytest.raises(_lib.MifError):
         two.enqueue_features(True)
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the agreed keys (small batch, bounded CPU sample)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1",
+                          "--batch", "4", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["unit"] == "frames/s"
+    assert "workload" in d["config"] and d["config"]["frames_per_step"] == 4
+    assert abs(d["value"] - 4 * 1000.0 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
