@@ -51,6 +51,9 @@ def parse_args():
                     help="frames start in pinned host memory: every step uploads its batch over PCIe on a copy "
                          "stream (overlapping the previous batch) and downloads the match summaries; the "
                          "PCIe-inclusive rate, never the headline value")
+    ap.add_argument("--native-pipeline", action="store_true",
+                    help="drive the same schedule through the library's own pipeline object (mif_video_*) "
+                         "instead of the calls made from this script; no per-stage times in that mode")
     ap.add_argument("--serial", action="store_true",
                     help="run the matcher of a batch after its feature phase instead of beside the next one's")
     return ap.parse_args()
@@ -210,6 +213,39 @@ def cpu_baseline(frames, budget_s, match=True):
                          "extract + match vs previous frame" if match else "extraction only")}
 
 
+def run_native(args, oda, torch, frames, local_rank, world, rank, dist):
+    """The timed loop over mif_video_submit_device / mif_video_collect (same schedule, made inside the
+    library); prints a reduced line (no roofline: the stage events belong to the handles inside)."""
+    vp = oda.VideoPipeline(args.width, args.height, args.channels, batch=args.batch, device=local_rank)
+    for _ in range(args.warmup):
+        vp.submit_device(frames.data_ptr(), args.batch)
+    vp.collect()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        vp.submit_device(frames.data_ptr(), args.batch)
+    res = vp.collect()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=frames.device if dist is not None and dist.get_backend() == "nccl" else "cpu")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "1080p SIFT extract+match frames/sec", "value": world * args.steps * args.batch / dt,
+                          "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "native pipeline object (mif_video_*), same schedule",
+                                     "frames_per_step": args.batch,
+                                     "keypoints_last_frame": list(res[-1].keypoints),
+                                     "good_matches_last_frame": res[-1].good_matches}}))
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -238,6 +274,8 @@ def main():
             dist.barrier()
 
     frames = torch.from_numpy(frames_np).to(torch.device("cuda", local_rank))
+    if args.native_pipeline:
+        return run_native(args, oda, torch, frames, local_rank, world, rank, dist)
     pipe = Pipeline(oda, torch, local_rank, args.width, args.height, args.batch, serial=args.serial,
                     channels=args.channels, match=not args.no_match)
 

@@ -267,6 +267,38 @@ typedef struct mif_match_pair {
 int mif_match_top2_batch_device(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq, int nd, int dim,
                                 int ld, int filter_mode, void* stream);
 
+/* ------------------------------------------------------- frame sequences -- */
+
+/* The -v loop of SIFT/main.cpp:103-153 (one extract_features call per frame, the previous
+ * frame's features kept for comparison) for batches of frames that stay on the GPU: every
+ * frame is extracted and matched against its predecessor (descriptor rows as
+ * common/kpmatch.h:127-142 builds them, nearest neighbour kept under the good-match rule
+ * of kpmatch.h:177-202). Two batched SIFT handles alternate and the matcher of batch k - 1
+ * runs beside the feature phase of batch k; nothing waits on the host before
+ * mif_video_collect. Frame 0 of a batch is matched against the last frame of the batch
+ * before it. */
+typedef struct mif_video mif_video;
+typedef struct mif_video_frame {
+    int32_t status;                      /* 0, or MIF_ERR_NO_KEYPOINTS (SIFT/sift.cpp:1257-1258) */
+    int32_t keypoints[MIF_SIFT_OCTAVES]; /* per octave, clamped to the list limit */
+    int32_t good_matches;                /* matches kept against the previous frame; -1 for the very first frame */
+    int32_t query_rows;                  /* descriptor rows of this frame */
+} mif_video_frame;
+
+int mif_video_create(int device, int width, int height, int channels, int batch, mif_video** out);
+int mif_video_destroy(mif_video* v);
+int mif_video_batch(const mif_video* v);
+/* Enqueues the extraction of nframes (<= batch) frames, u8 [nframes][height][width][channels],
+ * and the matching of the batch submitted before. _device: the frames are in device memory and
+ * must stay untouched until the next but one submit or a collect. _host: the frames are uploaded
+ * on a copy stream beside the previous batch's work (asynchronously when the memory is pinned);
+ * the buffer may be reused once the call after next has returned, or after a collect. */
+int mif_video_submit_device(mif_video* v, const void* d_frames, int nframes);
+int mif_video_submit_host(mif_video* v, const uint8_t* frames, int nframes);
+/* Waits for everything submitted and returns one record per frame since the last collect, in
+ * submission order. MIF_ERR_CAPACITY (nothing consumed) when more than `capacity` are waiting. */
+int mif_video_collect(mif_video* v, mif_video_frame* out, int capacity, int* n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,7 +62,19 @@ SYMBOLS = [
     ("mif_match_top2", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     ("mif_match_top2_scores", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     ("mif_match_top2_device", C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P]),
+    ("mif_video_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("mif_video_destroy", C.c_int, [_P]),
+    ("mif_video_batch", C.c_int, [_P]),
+    ("mif_video_submit_device", C.c_int, [_P, _P, C.c_int]),
+    ("mif_video_submit_host", C.c_int, [_P, _P, C.c_int]),
+    ("mif_video_collect", C.c_int, [_P, _P, C.c_int, _PI]),
 ]
+
+
+class VideoFrame(C.Structure):
+    """mif_video_frame of include/mi_features.h."""
+    _fields_ = [("status", C.c_int32), ("keypoints", C.c_int32 * 3), ("good_matches", C.c_int32),
+                ("query_rows", C.c_int32)]
 
 
 class MatchPair(C.Structure):

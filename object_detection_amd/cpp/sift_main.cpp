@@ -1,14 +1,18 @@
 // demo_coopcl_sift: the command line of the reference's SIFT demo (SIFT/main.cpp) on the GPU path.
 //   -m object.pgm scene.pgm -f x   extract both, match, homography; report to stdout (+ -o report.json)
-//   -v frames -f x                 per-frame extraction and matching against the previous frame;
-//                                  frames = "file.raw:WxHxC" or a printf pattern of PGM/PPM files
+//   -v frames -f x [-b N]          per-frame extraction and matching against the previous frame;
+//                                  frames = "file.raw:WxHxC" or a printf pattern of PGM/PPM files;
+//                                  -b N sends batches of N frames through the GPU-resident pipeline
 //   -i image -f x                  extract one image, print the feature count
 // -c (camera) needs a capture device and a display and is not available in this headless build.
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <iostream>
 
 #include "kpmatch.h"
+#include "../../include/mi_features.h"
 #include "parse_args.h"
 #include "sift.h"
 
@@ -98,6 +102,75 @@ static int call_stream_demo(const std::string& input, float offload)
     return 0;
 }
 
+// The same loop for whole batches of frames (-b N): the frames go through the library's
+// frame-sequence pipeline (mif_video_*), which keeps them on the GPU, overlaps the upload of one
+// batch with the work on the one before and matches every frame against its predecessor there.
+// Prints the per-frame lines of SIFT/main.cpp:129 once the results are in.
+static int call_stream_demo_batched(const std::string& input, int batch)
+{
+    mif::FrameReader reader(input);
+    if (!reader.isOpened()) {
+        std::cerr << "Error opening video stream or file:\t" << input << std::endl;
+        return -1;
+    }
+    const size_t max_frames = 100;
+    mif_video* pipe = nullptr;
+    int rows = 0, cols = 0, channels = 0;
+    // a submitted buffer must stay untouched until the call after next has returned: three in rotation
+    std::vector<unsigned char> staging[3];
+    std::vector<mif_video_frame> results;
+    size_t cnt_frames = 0, submitted = 0;
+    bool more = true;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto fail = [&](const char* what) {
+        std::cerr << what << ":\t" << mif_last_error() << std::endl;
+        if (pipe) mif_video_destroy(pipe);
+        return -1;
+    };
+    while (more && cnt_frames < max_frames) {
+        std::vector<unsigned char>& buf = staging[submitted % 3];
+        int n = 0;
+        while (n < batch && cnt_frames < max_frames) {
+            mif::Image frame;
+            if (!reader.read(frame)) { more = false; break; }
+            if (!pipe) {
+                rows = frame.rows; cols = frame.cols; channels = frame.channels();
+                if (mif_video_create(0, cols, rows, channels, batch, &pipe) != MIF_OK) return fail("pipeline");
+            }
+            if (frame.rows != rows || frame.cols != cols || frame.channels() != channels) {
+                std::cerr << "Frame " << cnt_frames << " differs in size from the first one" << std::endl;
+                more = false;
+                break;
+            }
+            const size_t bytes = (size_t)rows * cols * channels;
+            if (buf.size() < bytes * batch) buf.resize(bytes * batch);
+            std::copy(frame.data, frame.data + bytes, buf.begin() + bytes * n);
+            n++;
+            cnt_frames++;
+        }
+        if (n == 0) break;
+        if (mif_video_submit_host(pipe, buf.data(), n) != MIF_OK) return fail("submit");
+        submitted++;
+    }
+    if (cnt_frames == 0 || !pipe) return -1;
+    results.resize(cnt_frames);
+    int got = 0;
+    if (mif_video_collect(pipe, results.data(), (int)results.size(), &got) != MIF_OK) return fail("collect");
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    size_t total_good = 0;
+    for (int i = 0; i < got; i++) {
+        const mif_video_frame& f = results[i];
+        const int feats = f.status == 0 ? f.keypoints[0] + f.keypoints[1] + f.keypoints[2] : 0;
+        std::cout << "Frame id<" << i << "> Features: <" << feats << ">" << std::endl;
+        if (f.good_matches > 0) total_good += (size_t)f.good_matches;
+    }
+    std::cout << "Average time_ms:\t" << wall_ms / got << std::endl;
+    std::cout << "Overall time_ms:\t" << wall_ms << std::endl;
+    std::cout << "Frames:\t" << got << "\tgood matches:\t" << total_good << "\twall_ms:\t" << wall_ms << std::endl;
+    mif_video_destroy(pipe);
+    return 0;
+}
+
 // SIFT/main.cpp:155-174
 static int call_single_img_demo(const std::string& path, float offload)
 {
@@ -125,8 +198,11 @@ int main(int argc, char** argv)
         iargs::app_args::usage(std::cout);
     else if (args.app_mode == "-i")
         return call_single_img_demo(args.img_path_a, args.offload);
-    else if (args.app_mode == "-v")
+    else if (args.app_mode == "-v") {
+        const std::string b = option(argc, argv, "-b");
+        if (!b.empty() && std::atoi(b.c_str()) > 0) return call_stream_demo_batched(args.img_path_a, std::atoi(b.c_str()));
         return call_stream_demo(args.img_path_a, args.offload);
+    }
     else if (args.app_mode == "-c") {
         std::cerr << "Error opening video stream or file:\t(camera input is not available in this build)" << std::endl;
         return -1;

@@ -95,3 +95,27 @@ def test_stream_demo_on_raw_frames(tmp_path):
     out = subprocess.run([_need("demo_coopcl_Surf"), "-v", "%s:320x240x3" % raw, "-f", "0.3"],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "Average elapsed_time:" in out.stdout
+
+
+@pytest.mark.gpu
+def test_stream_demo_batched_equals_frame_by_frame(tmp_path):
+    """`-v ... -b N` (frames through the GPU-resident pipeline in batches) reports the feature counts and the
+    total of good matches that the frame-by-frame loop reports."""
+    from synth import blob_image
+    frames = [blob_image(320, 240, seed=5, channels=3, shift=(2 * t, t)) for t in range(7)]
+    raw = tmp_path / "clip.raw"
+    raw.write_bytes(b"".join(f.tobytes() for f in frames))
+
+    def run(extra):
+        out = subprocess.run([_need("demo_coopcl_sift"), "-v", "%s:320x240x3" % raw, "-f", "1"] + extra,
+                             capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+        assert out.returncode == 0, out.stdout + out.stderr
+        feats = [ln for ln in out.stdout.splitlines() if ln.startswith("Frame id<")]
+        total = [ln for ln in out.stdout.splitlines() if ln.startswith("Frames:")][0].split("\t")
+        return feats, total[1], total[3]
+
+    one, n1, g1 = run([])
+    for batch in ("3", "16"):
+        many, nb, gb = run(["-b", batch])
+        assert many == one and len(many) == 7
+        assert (nb, gb) == (n1, g1) and int(g1) > 0

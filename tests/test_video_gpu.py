@@ -1,0 +1,88 @@
+"""GPU parity of the frame-sequence pipeline (mif_video_*): per-frame keypoint counts and good matches
+against the previous frame, through the C ABI, against the CPU checker."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import object_detection_amd as oda
+from object_detection_amd import _lib
+import oracle_lib as orc
+from synth import blob_image
+
+pytestmark = pytest.mark.gpu
+
+W, H = 256, 192
+
+
+def _sequence(n, channels):
+    frames = [blob_image(W, H, seed=77, n_blobs=140, channels=channels, shift=(3 * t, 2 * t)) for t in range(n)]
+    frames[4] = np.full_like(frames[4], 128)             # a flat frame: status -1, nothing to match
+    return frames
+
+
+def _expected(frames, channels):
+    """(status, counts, good matches, query rows) per frame from the CPU checker."""
+    out, prev = [], None
+    for t, img in enumerate(frames):
+        S = orc.SiftOracle(W, H, channels)
+        rc = S.run(img)
+        if rc == 0:
+            counts = [S.count(o) for o in range(3)]
+            des = S.all_features()[3]
+        else:
+            counts, des = [0, 0, 0], np.zeros((0, 128), np.float32)
+        if t == 0:
+            good = -1
+        elif len(des) == 0:
+            good = 0
+        else:
+            _, d = orc.match_top2(oda.pack_sift_rows(des), oda.pack_sift_rows(prev))
+            mn = min(100.0, float(d[:, 0].astype(np.float64).min()))
+            good = int((d[:, 0].astype(np.float64) <= max(2.5 * mn, 0.35)).sum())
+        out.append((rc, counts, good, len(des)))
+        prev = des
+    return out
+
+
+@pytest.mark.parametrize("channels", [1, 3])
+def test_host_frames_in_uneven_batches(channels):
+    frames = _sequence(8, channels)
+    want = _expected(frames, channels)
+    vp = oda.VideoPipeline(W, H, channels, batch=3)
+    got = []
+    for lo, hi in ((0, 3), (3, 6), (6, 7)):              # full, full, partial batch
+        vp.submit_host(np.stack(frames[lo:hi]))
+    got += vp.collect()
+    vp.submit_host(np.stack(frames[7:8]))                # goes on after a collect; frame 7 follows frame 6
+    got += vp.collect()
+    assert len(got) == 8
+    for t, (g, w) in enumerate(zip(got, want)):
+        assert (g.status, list(g.keypoints), g.good_matches, g.query_rows) == w, t
+    assert vp.collect() == []
+    vp.close()
+
+
+def test_device_frames_and_argument_errors():
+    import torch
+    frames = _sequence(6, 3)
+    want = _expected(frames, 3)
+    dev = torch.device("cuda:0")
+    vp = oda.VideoPipeline(W, H, 3, batch=4)
+    a = torch.from_numpy(np.stack(frames[0:4])).to(dev)
+    b = torch.from_numpy(np.stack(frames[4:6])).to(dev)
+    torch.cuda.synchronize()
+    vp.submit_device(a.data_ptr(), 4)
+    vp.submit_device(b.data_ptr(), 2)
+    got = vp.collect()
+    assert [(g.status, list(g.keypoints), g.good_matches, g.query_rows) for g in got] == want
+    lib = oda.load_library()
+    assert lib.mif_video_submit_device(vp._h, C.c_void_p(a.data_ptr()), 5) == _lib.MIF_ERR_CAPACITY
+    assert lib.mif_video_submit_device(vp._h, None, 1) == _lib.MIF_ERR_INVALID_ARGUMENT
+    vp.submit_device(a.data_ptr(), 4)
+    n = C.c_int()
+    small = (_lib.VideoFrame * 2)()
+    assert lib.mif_video_collect(vp._h, small, 2, C.byref(n)) == _lib.MIF_ERR_CAPACITY and n.value == 0
+    rest = vp.collect()                                  # nothing was consumed by the failed call
+    assert len(rest) == 4 and rest[1].good_matches == want[1][2]
+    vp.close()
