@@ -94,3 +94,29 @@ class ShardedDatabaseMatcher:
         dists = allp[..., 2]
         wi, wd = merge_top2(scores, idxs, dists)
         return wi.cpu().numpy(), wd.cpu().numpy()
+
+
+def sharded_sequence(n_frames, process, group=None):
+    """Frame-to-previous-frame processing of a sequence split over the ranks of a process group.
+
+    Every rank takes one contiguous block of frames (`shard_range`); a block that does not start the
+    sequence is extended by the frame before it, so that its first frame is matched against the same
+    predecessor as in a single-device run, and that extra frame's record is dropped. `process(lo, hi)`
+    runs frames [lo, hi) in order and returns one record per frame (on the GPU: a VideoPipeline fed with
+    those frames). No collective runs on the data path; the records are gathered at the end, and every
+    rank returns the full list in frame order."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_range(n_frames, rank, world)
+    mine = []
+    if hi > lo:
+        start = lo - 1 if lo > 0 else lo
+        recs = list(process(start, hi))
+        if len(recs) != hi - start:
+            raise ValueError("process returned %d records for %d frames" % (len(recs), hi - start))
+        mine = recs[lo - start:]
+    if world == 1:
+        return mine
+    parts = [None] * world
+    dist.all_gather_object(parts, mine, group=group)
+    return [r for part in parts for r in part]

@@ -50,6 +50,19 @@ def _worker(rank, world, port, out_dir):
         S.run(blob_image(160, 120, seed=9, shift=(2 * t, t)), want_descriptors=False)
         counts[t] = torch.tensor([S.count(o) for o in range(3)])
     dist.all_reduce(counts)
+
+    # a sequence whose records depend on the previous frame: the shards must reproduce the single run
+    from object_detection_amd.distributed import sharded_sequence
+    calls = []
+
+    def process(lo, hi):
+        calls.append((lo, hi))
+        return [(t, -1 if t == lo else 1000 * t + (t - 1)) for t in range(lo, hi)]   # (frame, "match vs previous")
+
+    seq = sharded_sequence(7, process)
+    want = [(0, -1)] + [(t, 1000 * t + t - 1) for t in range(1, 7)]
+    ok_seq = seq == want and len(calls) == 1 and calls[0][0] == max(shard_range(7, rank, world)[0] - 1, 0)
+    ok_match = ok_match and ok_seq
     np.save(os.path.join(out_dir, "r%d.npy" % rank), np.array([int(ok_match)] + counts.flatten().tolist()))
     dist.barrier()
     dist.destroy_process_group()

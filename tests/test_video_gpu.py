@@ -86,3 +86,46 @@ def test_device_frames_and_argument_errors():
     rest = vp.collect()                                  # nothing was consumed by the failed call
     assert len(rest) == 4 and rest[1].good_matches == want[1][2]
     vp.close()
+
+
+def _rank_main(rank, world, port, out_dir):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import object_detection_amd as oda_
+    from object_detection_amd.distributed import sharded_sequence
+    frames = _sequence(9, 3)
+
+    def process(lo, hi):
+        vp = oda_.VideoPipeline(W, H, 3, batch=4)
+        for a in range(lo, hi, 4):
+            vp.submit_host(np.stack(frames[a:min(a + 4, hi)]))
+        recs = vp.collect()
+        vp.close()
+        return [tuple(r) for r in recs]
+
+    got = sharded_sequence(len(frames), process)
+    if rank == 0:
+        single = process(0, len(frames))
+        with open(os.path.join(out_dir, "ok"), "w") as fh:
+            fh.write("1" if got == single and len(got) == 9 else "0 %r %r" % (got, single))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_a_sequence(tmp_path):
+    """Two processes (gloo; they share this box's one GPU) take one block of the sequence each, the second
+    block extended by its predecessor frame: the gathered records equal a single run's."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.start_processes(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    assert open(tmp_path / "ok").read() == "1"
