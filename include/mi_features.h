@@ -288,6 +288,9 @@ typedef struct mif_video_frame {
 int mif_video_create(int device, int width, int height, int channels, int batch, mif_video** out);
 int mif_video_destroy(mif_video* v);
 int mif_video_batch(const mif_video* v);
+/* enable = 0: extraction only (batches submitted from now on are not matched and report
+ * good_matches = -1), e.g. for a batch of unrelated images. Default: matching on. */
+int mif_video_set_matching(mif_video* v, int enable);
 /* Enqueues the extraction of nframes (<= batch) frames, u8 [nframes][height][width][channels],
  * and the matching of the batch submitted before. _device: the frames are in device memory and
  * must stay untouched until the next but one submit or a collect. _host: the frames are uploaded

@@ -65,6 +65,7 @@ SYMBOLS = [
     ("mif_video_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("mif_video_destroy", C.c_int, [_P]),
     ("mif_video_batch", C.c_int, [_P]),
+    ("mif_video_set_matching", C.c_int, [_P, C.c_int]),
     ("mif_video_submit_device", C.c_int, [_P, _P, C.c_int]),
     ("mif_video_submit_host", C.c_int, [_P, _P, C.c_int]),
     ("mif_video_collect", C.c_int, [_P, _P, C.c_int, _PI]),

@@ -30,6 +30,7 @@ constexpr int kMatchDim = 127, kMatchLd = 128;   // the shifted descriptor row o
 struct BatchRecord {
     int nframes = 0;
     bool first_has_previous = false;    // frame 0 was matched (a frame preceded it)
+    bool matched = true;                // the batch went through the matcher
     int32_t* h_counts = nullptr;        // pinned [batch][8]
     int32_t* h_summary = nullptr;       // pinned [batch][2] = {kept, query rows}
 };
@@ -53,6 +54,7 @@ struct mif_video {
     int32_t* snap_cnt[3] = {nullptr, nullptr, nullptr};
     uint8_t* d_frames[2] = {nullptr, nullptr};  // upload targets of mif_video_submit_host (lazy)
     long long step = 0;                 // batches submitted
+    bool matching = true;               // frames are matched against their predecessors
     bool pending = false;               // the last submitted batch has not been matched yet
     int pending_frames = 0;
     std::deque<BatchRecord> inflight;   // submitted, not collected (oldest first)
@@ -137,6 +139,7 @@ int enqueue_match(mif_video* v, long long k, int nf)
         v->pairs.push_back(p);
     }
     rec.first_has_previous = k > 0;
+    if (!rec.matched) v->pairs.clear();          // the flag was taken when the batch was submitted
     if (!v->pairs.empty()) {
         rc = mif_match_top2_batch_device(v->matcher, v->pairs.data(), (int)v->pairs.size(), v->cap, v->cap, kMatchDim,
                                          kMatchLd, MIF_FILTER_SIFT, v->mstream);
@@ -178,6 +181,7 @@ int submit(mif_video* v, const void* d_frames, int nframes)
     rc = get_record(v, &rec);
     if (rc != MIF_OK) return rc;
     rec.nframes = nframes;
+    rec.matched = v->matching;
     v->inflight.push_back(rec);
     v->pending = true;
     v->pending_frames = nframes;
@@ -302,7 +306,7 @@ int mif_video_collect(mif_video* v, mif_video_frame* out, int capacity, int* n)
             mif_video_frame& f = out[at];
             f.status = c[kCntStatus];
             for (int o = 0; o < MIF_SIFT_OCTAVES; o++) f.keypoints[o] = c[o];
-            const bool matched = b > 0 || r.first_has_previous;
+            const bool matched = r.matched && (b > 0 || r.first_has_previous);
             f.good_matches = matched ? r.h_summary[2 * b] : -1;
             f.query_rows = matched ? r.h_summary[2 * b + 1] : c[kCntTotal];
         }
@@ -314,5 +318,12 @@ int mif_video_collect(mif_video* v, mif_video_frame* out, int capacity, int* n)
 }
 
 int mif_video_batch(const mif_video* v) { return v ? v->batch : MIF_ERR_INVALID_ARGUMENT; }
+
+int mif_video_set_matching(mif_video* v, int enable)
+{
+    if (!v) { mif::set_error("mif_video_set_matching: NULL handle"); return MIF_ERR_INVALID_ARGUMENT; }
+    v->matching = enable != 0;
+    return MIF_OK;
+}
 
 } // extern "C"

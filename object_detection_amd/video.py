@@ -28,6 +28,10 @@ class VideoPipeline:
     def __del__(self):
         self.close()
 
+    def set_matching(self, enable=True):
+        """Extraction only when disabled (good_matches = -1 for the batches submitted from then on)."""
+        _lib.check(self._lib.mif_video_set_matching(self._h, 1 if enable else 0))
+
     def submit_device(self, d_frames_ptr, nframes=None):
         """d_frames_ptr: device address of uint8 [nframes][height][width][channels]."""
         n = self.batch if nframes is None else nframes

@@ -60,6 +60,16 @@ def test_host_frames_in_uneven_batches(channels):
     for t, (g, w) in enumerate(zip(got, want)):
         assert (g.status, list(g.keypoints), g.good_matches, g.query_rows) == w, t
     assert vp.collect() == []
+    # extraction only: same counts, no match figures; matching resumes afterwards against the last frame
+    vp.set_matching(False)
+    vp.submit_host(np.stack(frames[0:3]))
+    off = vp.collect()
+    assert [(g.status, list(g.keypoints), g.query_rows) for g in off] == [(w[0], w[1], w[3]) for w in want[0:3]]
+    assert [g.good_matches for g in off] == [-1, -1, -1]
+    vp.set_matching(True)
+    vp.submit_host(np.stack(frames[3:4]))
+    on = vp.collect()
+    assert (on[0].status, list(on[0].keypoints), on[0].good_matches, on[0].query_rows) == want[3]
     vp.close()
 
 
