@@ -569,6 +569,35 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
 
 } // namespace
 
+namespace {
+
+// The interest points as mif_ipoint records (70 words: x, y, scale, orientation, laplacian, 0,
+// descriptor[64]; the layout of ccl_surf::Ipoint, ccl_surf.h:11-21), so that a host caller fetches
+// them with one copy.
+__global__ void k_pack_points(const float2* __restrict__ pos, const float* __restrict__ scale,
+                              const float* __restrict__ orient, const int* __restrict__ lap,
+                              const float* __restrict__ desc, const int* __restrict__ counts,
+                              uint32_t* __restrict__ out)
+{
+    constexpr int kWords = (int)(sizeof(mif_ipoint) / 4);
+    static_assert(kWords == 70, "mif_ipoint is 70 words");
+    const int total = counts[0] * kWords;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int p = i / kWords, k = i - p * kWords;
+        uint32_t v;
+        if (k >= 6) v = __float_as_uint(desc[(size_t)p * 64 + (k - 6)]);
+        else if (k == 0) v = __float_as_uint(pos[p].x);
+        else if (k == 1) v = __float_as_uint(pos[p].y);
+        else if (k == 2) v = __float_as_uint(scale[p]);
+        else if (k == 3) v = __float_as_uint(orient[p]);
+        else if (k == 4) v = (uint32_t)lap[p];
+        else v = 0u;
+        out[i] = v;
+    }
+}
+
+} // namespace
+
 struct mif_surf {
     int device = 0, W = 0, H = 0, C = 1;
     hipStream_t stream = nullptr;
@@ -579,10 +608,14 @@ struct mif_surf {
     int nms_max_h = 0;
     uint8_t* d_pixels = nullptr;
     float* integral = nullptr;
+    // responses | laplacians | mask | rowcnt live in ONE allocation that a single memset clears per frame
+    void* cleared = nullptr;
+    size_t cleared_bytes = 0;
     float* responses = nullptr;
     int* laplacians = nullptr;
     unsigned long long* mask = nullptr;
     int* rowcnt = nullptr;
+    mif_ipoint* packed = nullptr;        // the points as mif_ipoint records, for a single download
     int* rowoff = nullptr;
     int* counts = nullptr;               // {points (cut at 8000), raw total}
     float2* pos = nullptr;
@@ -591,16 +624,14 @@ struct mif_surf {
     float* orient = nullptr;
     float* desc = nullptr;
     int* h_counts = nullptr;
-    std::vector<float> h_f;              // staging for mif_surf_run
-    std::vector<int> h_i;
 };
 
 namespace {
 
 void surf_free(mif_surf* s)
 {
-    (void)hipFree(s->d_pixels); (void)hipFree(s->integral); (void)hipFree(s->responses);
-    (void)hipFree(s->laplacians); (void)hipFree(s->mask); (void)hipFree(s->rowcnt); (void)hipFree(s->rowoff);
+    (void)hipFree(s->d_pixels); (void)hipFree(s->integral); (void)hipFree(s->cleared); (void)hipFree(s->rowoff);
+    (void)hipFree(s->packed);
     (void)hipFree(s->counts); (void)hipFree(s->pos); (void)hipFree(s->scale); (void)hipFree(s->lap);
     (void)hipFree(s->orient); (void)hipFree(s->desc);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
@@ -645,10 +676,20 @@ int surf_create_impl(mif_surf* s)
     const size_t px = (size_t)s->W * s->H;
     MIF_HIP(hipMalloc(&s->d_pixels, px * s->C));
     MIF_HIP(hipMalloc(&s->integral, px * sizeof(float)));
-    MIF_HIP(hipMalloc(&s->responses, s->pool * sizeof(float)));
-    MIF_HIP(hipMalloc(&s->laplacians, s->pool * sizeof(int)));
-    MIF_HIP(hipMalloc(&s->mask, (size_t)std::max(rows, 1) * s->nms.words * sizeof(unsigned long long)));
-    MIF_HIP(hipMalloc(&s->rowcnt, (size_t)std::max(rows, 1) * sizeof(int)));
+    {
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t b_resp = up(s->pool * sizeof(float)), b_lap = up(s->pool * sizeof(int));
+        const size_t b_mask = up((size_t)std::max(rows, 1) * s->nms.words * sizeof(unsigned long long));
+        const size_t b_cnt = up((size_t)std::max(rows, 1) * sizeof(int));
+        s->cleared_bytes = b_resp + b_lap + b_mask + b_cnt;
+        MIF_HIP(hipMalloc(&s->cleared, s->cleared_bytes));
+        char* base = (char*)s->cleared;
+        s->responses = (float*)base;
+        s->laplacians = (int*)(base + b_resp);
+        s->mask = (unsigned long long*)(base + b_resp + b_lap);
+        s->rowcnt = (int*)(base + b_resp + b_lap + b_mask);
+    }
+    MIF_HIP(hipMalloc(&s->packed, (size_t)kMaxIpts * sizeof(mif_ipoint)));
     MIF_HIP(hipMalloc(&s->rowoff, (size_t)std::max(rows, 1) * sizeof(int)));
     MIF_HIP(hipMalloc(&s->counts, 2 * sizeof(int)));
     MIF_HIP(hipMemset(s->counts, 0, 2 * sizeof(int)));
@@ -673,19 +714,16 @@ int surf_enqueue(mif_surf* s, const void* d_pixels)
     hipStream_t st = s->stream;
     const int w = s->W, h = s->H;
     MIF_HIP(hipEventRecord(s->ev0, st));
+    // layers that are empty keep zero-sized slots; the pools are cleared so that
+    // positions no work item writes read as zero, as in freshly allocated buffers
+    // (one memset: response and laplacian pools, acceptance mask, row counts)
+    MIF_HIP(hipMemsetAsync(s->cleared, 0, s->cleared_bytes, st));
     hipLaunchKernelGGL(k_scan_rows, dim3((h + 3) / 4), dim3(256), 0, st, (const uint8_t*)d_pixels, s->integral, w, h,
                        s->C);
     hipLaunchKernelGGL(k_scan_cols, dim3((w + 63) / 64), dim3(64), 0, st, s->integral, w, h);
-    // layers that are empty keep zero-sized slots; the pools are cleared so that
-    // positions no work item writes read as zero, as in freshly allocated buffers
-    MIF_HIP(hipMemsetAsync(s->responses, 0, s->pool * sizeof(float), st));
-    MIF_HIP(hipMemsetAsync(s->laplacians, 0, s->pool * sizeof(int), st));
     const int lw = std::max(s->tab.l[0].w, 1), lh = std::max(s->tab.l[0].h, 1);
     hipLaunchKernelGGL(k_hessian, dim3((lw + 15) / 16, (lh + 15) / 16, kLayers), dim3(256), 0, st,
                        (const float*)s->integral, w, h, s->tab, s->responses, s->laplacians);
-    MIF_HIP(hipMemsetAsync(s->rowcnt, 0, (size_t)std::max(s->nms.rows, 1) * sizeof(int), st));
-    MIF_HIP(hipMemsetAsync(s->mask, 0, (size_t)std::max(s->nms.rows, 1) * s->nms.words * sizeof(unsigned long long),
-                           st));
     hipLaunchKernelGGL(k_nms_mark, dim3(s->nms.words, s->nms_max_h, kNms), dim3(64), 0, st, s->tab, s->nms,
                        (const float*)s->responses, (const int*)s->laplacians, kThres, s->mask, s->rowcnt);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, (const int*)s->rowcnt, s->rowoff, s->nms.rows,
@@ -700,6 +738,9 @@ int surf_enqueue(mif_surf* s, const void* d_pixels)
     hipLaunchKernelGGL(k_descriptor, dim3(kMaxIpts), dim3(256), 0, st, (const float*)s->integral, w, h,
                        (const float2*)s->pos, (const float*)s->scale, (const float*)s->orient, (const int*)s->counts,
                        s->desc);
+    hipLaunchKernelGGL(k_pack_points, dim3(64), dim3(256), 0, st, (const float2*)s->pos, (const float*)s->scale,
+                       (const float*)s->orient, (const int*)s->lap, (const float*)s->desc, (const int*)s->counts,
+                       reinterpret_cast<uint32_t*>(s->packed));
     MIF_HIP(hipGetLastError());
     MIF_HIP(hipEventRecord(s->ev1, st));
     return MIF_OK;
@@ -792,26 +833,7 @@ int mif_surf_run(mif_surf* s, const uint8_t* pixels, mif_ipoint* points, int cap
         return MIF_ERR_CAPACITY;
     }
     if (n == 0) return MIF_OK;
-    s->h_f.resize((size_t)n * (2 + 1 + 1 + 64));
-    s->h_i.resize(n);
-    float* hpos = s->h_f.data();
-    float* hscale = hpos + 2 * (size_t)n;
-    float* hori = hscale + n;
-    float* hdesc = hori + n;
-    MIF_HIP(hipMemcpy(hpos, s->pos, (size_t)n * sizeof(float2), hipMemcpyDeviceToHost));
-    MIF_HIP(hipMemcpy(hscale, s->scale, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-    MIF_HIP(hipMemcpy(hori, s->orient, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
-    MIF_HIP(hipMemcpy(hdesc, s->desc, (size_t)n * 64 * sizeof(float), hipMemcpyDeviceToHost));
-    MIF_HIP(hipMemcpy(s->h_i.data(), s->lap, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
-    for (int i = 0; i < n; i++) {
-        mif_ipoint& p = points[i];
-        p.x = hpos[2 * i]; p.y = hpos[2 * i + 1];
-        p.scale = hscale[i];
-        p.orientation = hori[i];
-        p.laplacian = s->h_i[i];
-        p.clusterIndex = 0;
-        memcpy(p.descriptor, hdesc + (size_t)i * 64, 64 * sizeof(float));
-    }
+    MIF_HIP(hipMemcpy(points, s->packed, (size_t)n * sizeof(mif_ipoint), hipMemcpyDeviceToHost));
     *count = n;
     return MIF_OK;
 }
