@@ -1234,6 +1234,9 @@ struct mif_sift {
     hipEvent_t ev_stage[kOctaves][3] = {};   // pyramid phase: before base, before blur, after blur
     hipEvent_t ev_feat[kOctaves][3] = {};    // feature phase: before detection, after emission, at the end
     int pyramid_frames = 0;                  // frames whose scale spaces await the feature phase
+    // streams and events for running the octaves' feature kernels side by side (small inputs)
+    hipStream_t aux[kOctaves] = {};          // [0] unused: octave 0 stays on `stream`
+    hipEvent_t ev_fork = nullptr, ev_scan[kOctaves] = {}, ev_join[kOctaves] = {};
 };
 
 namespace {
@@ -1339,36 +1342,54 @@ int enqueue_features(mif_sift* s, int want_desc)
     hipStream_t st = s->stream;
     const int nf = s->pyramid_frames;
     const bool tm = s->timing;
+    // Little work (up to about one 1080p frame): every kernel below is a chain of latencies, not a
+    // throughput problem, so the octaves run side by side on streams of their own. Only the row scans
+    // are ordered octave after octave (they accumulate the list offsets the later kernels read).
+    const bool side_by_side = !tm && s->aux[1] && (size_t)nf * s->oct[0].items <= ((size_t)1 << 21);
+    if (side_by_side) {
+        MIF_HIP(hipEventRecord(s->ev_fork, st));
+        for (int o = 1; o < kOctaves; o++) MIF_HIP(hipStreamWaitEvent(s->aux[o], s->ev_fork, 0));
+    }
+    int last_scanned = -1;                      // latest octave whose row scan has been enqueued
     for (int o = 0; o < kOctaves; o++) {
         OctaveBuf& O = s->oct[o];
         if (O.items == 0) continue;
+        hipStream_t so = (side_by_side && o > 0) ? s->aux[o] : st;
         const size_t pyr_stride = O.items * kLevels, dog_stride = O.items * (kLevels - 1);
+        const size_t grad_stride = O.items * kIntervals;
         if (tm) MIF_HIP(hipEventRecord(s->ev_feat[o][0], st));
-        MIF_HIP(hipMemsetAsync(O.rowcnt, 0, (size_t)nf * O.rows * sizeof(int), st));
-        MIF_HIP(hipMemsetAsync(O.mask, 0, (size_t)nf * O.rows * O.words * sizeof(unsigned long long), st));
+        MIF_HIP(hipMemsetAsync(O.rowcnt, 0, (size_t)nf * O.rows * sizeof(int), so));
+        MIF_HIP(hipMemsetAsync(O.mask, 0, (size_t)nf * O.rows * O.words * sizeof(unsigned long long), so));
         {
             const int nbx = (O.w + 4 * kDetCols - 1) / (4 * kDetCols), nby = (O.h + kDetRows - 1) / kDetRows;
             const int nblocks = nbx * nby * nf;
-            hipLaunchKernelGGL(k_detect, dim3(8 * ((nblocks + 7) / 8)), dim3(256), 0, st, (const float*)O.dog,
+            hipLaunchKernelGGL(k_detect, dim3(8 * ((nblocks + 7) / 8)), dim3(256), 0, so, (const float*)O.dog,
                                dog_stride, O.mask, O.rowcnt, O.w, O.h, O.words, o, nbx, nby, nblocks);
         }
-        hipLaunchKernelGGL(k_scan_rows, dim3(nf), dim3(1024), 0, st, (const int*)O.rowcnt, O.rowoff, O.rows, O.maxf,
+        const bool grad_first = side_by_side && want_desc && O.maxf > 0;
+        if (grad_first)                         // independent of the detector: ahead of the wait below
+            hipLaunchKernelGGL(k_gradient, dim3((O.w + 127) / 128, (O.h + 2 * kGradRows - 1) / (2 * kGradRows), kIntervals * nf),
+                               dim3(256), 0, so, (const float*)O.pyr, pyr_stride, O.grad, grad_stride, O.w, O.h);
+        if (side_by_side && last_scanned >= 0) MIF_HIP(hipStreamWaitEvent(so, s->ev_scan[last_scanned], 0));
+        hipLaunchKernelGGL(k_scan_rows, dim3(nf), dim3(1024), 0, so, (const int*)O.rowcnt, O.rowoff, O.rows, O.maxf,
                            o, s->counts);
+        if (side_by_side) MIF_HIP(hipEventRecord(s->ev_scan[o], so));
+        last_scanned = o;
         if (O.maxf > 0) {
-            hipLaunchKernelGGL(k_emit, dim3((O.maxf + 255) / 256, nf), dim3(256), 0, st, (const float*)O.dog, dog_stride,
+            hipLaunchKernelGGL(k_emit, dim3((O.maxf + 255) / 256, nf), dim3(256), 0, so, (const float*)O.dog, dog_stride,
                                (const unsigned long long*)O.mask, (const int*)O.rowcnt, (const int*)O.rowoff, O.w,
                                O.h, O.words, o, O.maxf, s->cap, (const int*)s->counts, s->kp);
             if (tm) MIF_HIP(hipEventRecord(s->ev_feat[o][1], st));
             if (want_desc) {
-                const size_t grad_stride = O.items * kIntervals;
-                hipLaunchKernelGGL(k_gradient, dim3((O.w + 127) / 128, (O.h + 2 * kGradRows - 1) / (2 * kGradRows), kIntervals * nf),
-                                   dim3(256), 0, st,
-                                   (const float*)O.pyr, pyr_stride, O.grad, grad_stride, O.w, O.h);
-                hipLaunchKernelGGL(k_orientation, dim3(std::min((O.maxf + 3) / 4, std::max(kOriBlocks, kOriBlocksTotal / nf)), nf), dim3(64), 0, st,
+                if (!grad_first)
+                    hipLaunchKernelGGL(k_gradient, dim3((O.w + 127) / 128, (O.h + 2 * kGradRows - 1) / (2 * kGradRows), kIntervals * nf),
+                                       dim3(256), 0, so,
+                                       (const float*)O.pyr, pyr_stride, O.grad, grad_stride, O.w, O.h);
+                hipLaunchKernelGGL(k_orientation, dim3(std::min((O.maxf + 3) / 4, std::max(kOriBlocks, kOriBlocksTotal / nf)), nf), dim3(64), 0, so,
                                    (const float4*)s->kp,
                                    (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap, (const int*)s->counts,
                                    s->orient, s->ori_bins);
-                hipLaunchKernelGGL(k_descriptor, dim3(std::min(O.maxf, std::max(kDescBlocks, kDescBlocksTotal / nf)), nf), dim3(128), 0, st,
+                hipLaunchKernelGGL(k_descriptor, dim3(std::min(O.maxf, std::max(kDescBlocks, kDescBlocksTotal / nf)), nf), dim3(128), 0, so,
                                    (const float4*)s->kp,
                                    (const float*)s->orient, (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap,
                                    (const int*)s->counts, s->desc);
@@ -1377,6 +1398,10 @@ int enqueue_features(mif_sift* s, int want_desc)
             MIF_HIP(hipEventRecord(s->ev_feat[o][1], st));
         }
         if (tm) MIF_HIP(hipEventRecord(s->ev_feat[o][2], st));
+        if (side_by_side && o > 0) {
+            MIF_HIP(hipEventRecord(s->ev_join[o], so));
+            MIF_HIP(hipStreamWaitEvent(st, s->ev_join[o], 0));
+        }
     }
     if (tm) { s->timed_frame = true; s->timed_desc = want_desc != 0; }
     hipLaunchKernelGGL(k_finish, dim3((nf + 63) / 64), dim3(64), 0, st, s->counts, nf, want_desc);
@@ -1406,6 +1431,12 @@ void free_all(mif_sift* s)
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->ev_dep) (void)hipEventDestroy(s->ev_dep);
+    if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+    for (int o = 0; o < kOctaves; o++) {
+        if (s->ev_scan[o]) (void)hipEventDestroy(s->ev_scan[o]);
+        if (s->ev_join[o]) (void)hipEventDestroy(s->ev_join[o]);
+        if (s->aux[o]) (void)hipStreamDestroy(s->aux[o]);
+    }
     for (int o = 0; o < kOctaves; o++)
         for (int i = 0; i < 3; i++) {
             if (s->ev_stage[o][i]) (void)hipEventDestroy(s->ev_stage[o][i]);
@@ -1421,6 +1452,12 @@ int create_impl(mif_sift* s)
     MIF_HIP(hipEventCreate(&s->ev0));
     MIF_HIP(hipEventCreate(&s->ev1));
     MIF_HIP(hipEventCreateWithFlags(&s->ev_dep, hipEventDisableTiming));
+    MIF_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    for (int o = 0; o < kOctaves; o++) {
+        if (o > 0) MIF_HIP(hipStreamCreateWithFlags(&s->aux[o], hipStreamNonBlocking));
+        MIF_HIP(hipEventCreateWithFlags(&s->ev_scan[o], hipEventDisableTiming));
+        MIF_HIP(hipEventCreateWithFlags(&s->ev_join[o], hipEventDisableTiming));
+    }
     s->cap = 0;
     for (int o = 0; o < kOctaves; o++) {
         OctaveBuf& O = s->oct[o];
