@@ -192,10 +192,11 @@ __global__ void k_decimate(const float* __restrict__ src, size_t src_stride, flo
 
 // ---------------------------------------------------------------- blur level
 //
-// One launch per pyramid level: dst = V(H(src)) with the level's taps, and
-// (level >= 1) dog = dst - src, i.e. kBlurH + kBlurV + kDiff of the reference
-// (sift.cpp:213-261) in one pass over HBM: 4 B read + 4 or 8 B written per
-// pixel instead of 16 + 12.
+// One launch per pyramid level: dst = V(H(src)) with the level's taps, i.e.
+// kBlurH + kBlurV of the reference (sift.cpp:213-245) in one pass over HBM:
+// 4 B read + 4 B written per pixel instead of 8 + 8. The DoG images of kDiff
+// (sift.cpp:247-262) are not stored at all: the detector and the emitter, their
+// only readers, subtract neighbouring levels where they need a DoG sample.
 //
 // Both 1-D passes apply taps 0 .. 2*FR-1 only (the reference's loops stop one
 // short of the filter width, sift.cpp:222,238) in ascending order as an fmaf
@@ -206,8 +207,7 @@ __global__ void k_decimate(const float* __restrict__ src, size_t src_stride, flo
 // of others) and on the instructions spent per pixel, so
 //  * ONE LDS array holds first the (64+2FR-1)^2 input window, transposed, and
 //    then the horizontal pass's result: every thread moves its horizontal
-//    window (and the window's centre, which the DoG needs) into registers
-//    before the first result is written;
+//    window into registers before the first result is written;
 //  * staging: a wave takes one row of the window per step (row index and bounds
 //    are wave-uniform, lanes run along x) with a scalar row base, issues all
 //    its loads before the first LDS store, and stores TRANSPOSED (odd pitch);
@@ -222,10 +222,10 @@ __global__ void k_decimate(const float* __restrict__ src, size_t src_stride, flo
 // per XCD (consecutive blocks go to consecutive XCDs), so that neighbouring
 // tiles, which share halo rows and columns, meet in the same L2.
 
-template <int FR, bool DOG>
+template <int FR>
 __global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ src, size_t src_stride,
-                                                    float* __restrict__ dst, float* __restrict__ dog,
-                                                    size_t pyr_stride, size_t dog_stride, int w, int h, Taps taps,
+                                                    float* __restrict__ dst, size_t pyr_stride, int w, int h,
+                                                    Taps taps,
                                                     int tiles_x, int tiles_y, int ntiles,
                                                     const float* __restrict__ zero_row)
 {
@@ -260,7 +260,6 @@ __global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ sr
     const int x0 = (rem - ty * tiles_x) * TW, y0 = ty * TH;
     src += (size_t)z * src_stride;
     dst += (size_t)z * pyr_stride;
-    if (DOG) dog += (size_t)z * dog_stride;
 
     // stage the input window
     {
@@ -298,14 +297,6 @@ __global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ sr
     // vertical-pass mapping: columns 2 xp, 2 xp + 1, rows R yc .. R yc + R - 1
     const int xp = tid & 31;
     const int yc = tid >> 5;
-    v2f centre[R];
-    if (DOG) {
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const float* c = &s_in[(2 * xp + FR) * PT + (yc * R + r + FR)];
-            centre[r] = (v2f){c[0], c[PT]};
-        }
-    }
 
     // horizontal pass: chunks start at columns 0, 21, 42; the shared columns are written
     // twice with the same value
@@ -364,18 +355,11 @@ __global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ sr
             const int gy = y0 + yc * R + r;
             if (gy < h && gx < w) {
                 const size_t at = (size_t)gy * w + gx;
-                v2f d = acc[r];
-                if (DOG) d = acc[r] - centre[r];
                 if (pair) {
                     *(v2f*)&dst[at] = acc[r];
-                    if (DOG) *(v2f*)&dog[at] = d;
                 } else {
                     dst[at] = acc[r].x;
-                    if (DOG) dog[at] = d.x;
-                    if (gx + 1 < w) {
-                        dst[at + 1] = acc[r].y;
-                        if (DOG) dog[at + 1] = d.y;
-                    }
+                    if (gx + 1 < w) dst[at + 1] = acc[r].y;
                 }
             }
         }
@@ -481,18 +465,29 @@ __device__ __forceinline__ bool finish_pixel(const NewtonStep& r, float cur, int
 // contrast tests. Returns true when the reference would append a feature; *out
 // is that feature. The refinement steps tx, ty, ts but keeps reading the same
 // three DoG images, as the reference does.
-__device__ bool refine_pixel(const float* __restrict__ dp, const float* __restrict__ dc,
-                             const float* __restrict__ dn, int w, int h, int s, int o, int x, int y, float4* out)
+//
+// The DoG images are not stored: DoG[d] = level d+1 - level d (kDiff, sift.cpp:256-260) is one float
+// subtraction and is evaluated where a sample is needed, from the pyramid `pyr` ([6][h][w] of the frame).
+__device__ bool refine_pixel(const float* __restrict__ pyr, size_t items, int w, int h, int s, int o, int x, int y,
+                             float4* out)
 {
+    // previous / current / next DoG image of level s: DoG[s-1], DoG[s], DoG[s+1]
+    const float* l0 = pyr + (size_t)(s - 1) * items;
+    const float* l1 = l0 + items;
+    const float* l2 = l1 + items;
+    const float* l3 = l2 + items;
+    auto dp = [&](int i) { return l1[i] - l0[i]; };
+    auto dc = [&](int i) { return l2[i] - l1[i]; };
+    auto dn = [&](int i) { return l3[i] - l2[i]; };
     NewtonStep r;
     int tx = x, ty = y, ts = s, iter;
     for (iter = 0; iter < kInterpSteps; iter++) {
         const int i0 = ty * w + tx;
         Stencil t;
-        t.c00 = dc[i0]; t.cxp = dc[i0 + 1]; t.cxm = dc[i0 - 1]; t.cyp = dc[i0 + w]; t.cym = dc[i0 - w];
-        t.cpp = dc[i0 + w + 1]; t.cmm = dc[i0 - w - 1]; t.cpm = dc[i0 + w - 1]; t.cmp = dc[i0 - w + 1];
-        t.n00 = dn[i0]; t.nxp = dn[i0 + 1]; t.nxm = dn[i0 - 1]; t.nyp = dn[i0 + w]; t.nym = dn[i0 - w];
-        t.p00 = dp[i0]; t.pxp = dp[i0 + 1]; t.pxm = dp[i0 - 1]; t.pyp = dp[i0 + w]; t.pym = dp[i0 - w];
+        t.c00 = dc(i0); t.cxp = dc(i0 + 1); t.cxm = dc(i0 - 1); t.cyp = dc(i0 + w); t.cym = dc(i0 - w);
+        t.cpp = dc(i0 + w + 1); t.cmm = dc(i0 - w - 1); t.cpm = dc(i0 + w - 1); t.cmp = dc(i0 - w + 1);
+        t.n00 = dn(i0); t.nxp = dn(i0 + 1); t.nxm = dn(i0 - 1); t.nyp = dn(i0 + w); t.nym = dn(i0 - w);
+        t.p00 = dp(i0); t.pxp = dp(i0 + 1); t.pxm = dp(i0 - 1); t.pyp = dp(i0 + w); t.pym = dp(i0 - w);
         r = newton_step(t);
         if (r.singular) return false;
         if (step_converged(r)) break;
@@ -504,15 +499,17 @@ __device__ bool refine_pixel(const float* __restrict__ dp, const float* __restri
         if (ts < 1 || ts > kIntervals) return false;
     }
     if (iter >= kInterpSteps) return false;
-    const float cur = ts == 1 ? dp[ty * w + tx] : ts == 2 ? dc[ty * w + tx] : dn[ty * w + tx];   // sift.cpp:400
+    const int ic = ty * w + tx;
+    const float cur = ts == 1 ? dp(ic) : ts == 2 ? dc(ic) : dn(ic);   // sift.cpp:400
     return finish_pixel(r, cur, tx, ty, ts, o, out);
 }
 
 // Detection pass (sift.cpp:276-322, then the refinement), streaming form
 // without a staging tile. A wave owns a strip of 62 columns (lanes 1..62; lanes
 // 0 and 63 only carry the neighbouring columns) and walks kDetRows rows of it.
-// Per row it loads one value per DoG image and lane (five coalesced 256-byte
-// loads, issued a group of rows ahead), obtains the left / right neighbours
+// Per row it loads one value per pyramid level and lane (six coalesced 256-byte
+// loads, issued a group of rows ahead), forms the five DoG values (level l+1 -
+// level l, kDiff of sift.cpp:256-260), obtains the left / right neighbours
 // from the adjacent lanes, and keeps the 3x3 neighbourhood of every image in
 // registers, sliding down one row at a time. The test is branch-free:
 // border, |D| > 0.0108333, and "v > every neighbour" evaluated as
@@ -527,7 +524,7 @@ constexpr int kDetRows = 32;        // rows per block
 constexpr int kDetGroup = 4;        // rows loaded ahead
 constexpr int kDetQueue = 4096;
 
-__global__ __launch_bounds__(256) void k_detect(const float* __restrict__ dog, size_t dog_stride,
+__global__ __launch_bounds__(256) void k_detect(const float* __restrict__ pyr, size_t pyr_stride,
                                                 unsigned long long* __restrict__ mask, int* __restrict__ rowcnt,
                                                 int w, int h, int words, int o, int nbx, int nby, int nblocks)
 {
@@ -543,19 +540,23 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ dog, s
     const int x = (bx * 4 + wave) * kDetCols + lane - 1;
     const int y0 = by * kDetRows;
     const size_t items = (size_t)w * h;
-    dog += (size_t)f * dog_stride;
+    pyr += (size_t)f * pyr_stride;
     if (threadIdx.x == 0) s_ncand = 0;
     __syncthreads();
     const bool xin = x >= 0 && x < w;
     const bool xtest = lane >= 1 && lane <= kDetCols && x > kBorder && x < w - kBorder;
-    auto load_row = [&](int y, float v[kLevels - 1]) {
+    // one row of the six pyramid levels; the five DoG values are formed when the row enters the window
+    auto load_row = [&](int y, float v[kLevels]) {
         const bool ok = xin && y >= 0 && y < h;
 #pragma unroll
-        for (int l = 0; l < kLevels - 1; l++) v[l] = ok ? dog[l * items + (size_t)y * w + x] : 0.0f;
+        for (int l = 0; l < kLevels; l++) v[l] = ok ? pyr[l * items + (size_t)y * w + x] : 0.0f;
     };
     // nb[l][r][c]: rows r = 0..2 <-> y-1, y, y+1; columns c = 0..2 <-> x-1, x, x+1
     float nb[kLevels - 1][3][3];
-    auto push_row = [&](const float v[kLevels - 1]) {
+    auto push_row = [&](const float lv[kLevels]) {
+        float v[kLevels - 1];
+#pragma unroll
+        for (int l = 0; l < kLevels - 1; l++) v[l] = lv[l + 1] - lv[l];      // kDiff, sift.cpp:256-260
 #pragma unroll
         for (int l = 0; l < kLevels - 1; l++) {
 #pragma unroll
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ dog, s
         }
     };
     {
-        float v[kLevels - 1];
+        float v[kLevels];
 #pragma unroll
         for (int l = 0; l < kLevels - 1; l++)
 #pragma unroll
@@ -601,8 +602,7 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ dog, s
                 const int y = y0 + ((e >> 16) & 0xfff);
                 const int cx = (e & 0xffff) - 1 + bx * 4 * kDetCols;
                 float4 kp;
-                if (refine_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o, cx, y,
-                                 &kp)) {
+                if (refine_pixel(pyr, items, w, h, s, o, cx, y, &kp)) {
                     const size_t r = (size_t)f * kIntervals * h + (s - 1) * h + y;
                     atomicOr(&mask[r * words + (cx >> 6)], 1ull << (cx & 63));
                     atomicAdd(&rowcnt[r], 1);
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ dog, s
             __syncthreads();
         }
         if (done) break;
-        float ahead[kDetGroup][kLevels - 1];
+        float ahead[kDetGroup][kLevels];
 #pragma unroll
         for (int g = 0; g < kDetGroup; g++) load_row(y0 + g0 + g + 1, ahead[g]);
 #pragma unroll
@@ -708,7 +708,7 @@ __device__ __forceinline__ int octave_base(const int* counts, int o)
 // bisection over the exclusive scan, then the (p - rowoff)-th set bit of that
 // row's bitmask, re-refines the pixel (the refinement is a pure function of the
 // DoG stack) and writes the keypoint at base(octave) + p, i.e. in raster order.
-__global__ __launch_bounds__(256) void k_emit(const float* __restrict__ dog, size_t dog_stride,
+__global__ __launch_bounds__(256) void k_emit(const float* __restrict__ pyr, size_t pyr_stride,
                                               const unsigned long long* __restrict__ mask,
                                               const int* __restrict__ rowcnt, const int* __restrict__ rowoff, int w,
                                               int h, int words, int o, int maxf, int cap,
@@ -746,9 +746,9 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ dog, siz
     const int s = r / h + 1;
     const int y = r - (s - 1) * h;
     const size_t items = (size_t)w * h;
-    dog += (size_t)f * dog_stride;
+    pyr += (size_t)f * pyr_stride;
     float4 out;
-    refine_pixel(dog + (s - 1) * items, dog + s * items, dog + (s + 1) * items, w, h, s, o, x, y, &out);
+    refine_pixel(pyr, items, w, h, s, o, x, y, &out);
     kp[(size_t)f * cap + octave_base(counts, o) + p] = out;
 }
 
@@ -1142,7 +1142,6 @@ struct OctaveBuf {
     // every buffer holds `batch` frames back to back
     float* base = nullptr;                 // [h][w] input of level 0
     float* pyr = nullptr;                  // [6][h][w]
-    float* dog = nullptr;                  // [5][h][w]
     float2* grad = nullptr;                // [3][h][w] gradient {mag, theta} of levels 1..3
     unsigned long long* mask = nullptr;    // [3*h][words]
     int* rowcnt = nullptr;                 // [3*h]
@@ -1243,29 +1242,25 @@ struct mif_sift {
 namespace {
 
 template <int FR>
-void launch_blur_fr(const float* src, size_t src_stride, float* dst, float* dog, size_t pyr_stride, size_t dog_stride,
-                    int w, int h, int nframes, const Taps& t, const float* zero_row, hipStream_t st)
+void launch_blur_fr(const float* src, size_t src_stride, float* dst, size_t pyr_stride, int w, int h, int nframes,
+                    const Taps& t, const float* zero_row, hipStream_t st)
 {
     const int tiles_x = (w + kBlurTile - 1) / kBlurTile, tiles_y = (h + kBlurTile - 1) / kBlurTile;
     const int ntiles = tiles_x * tiles_y * nframes;
     const int blocks = 8 * ((ntiles + 7) / 8);             // one equal share of the tiles per XCD
-    if (dog)
-        hipLaunchKernelGGL((k_blur_level<FR, true>), dim3(blocks), dim3(256), 0, st, src, src_stride, dst, dog,
-                           pyr_stride, dog_stride, w, h, t, tiles_x, tiles_y, ntiles, zero_row);
-    else
-        hipLaunchKernelGGL((k_blur_level<FR, false>), dim3(blocks), dim3(256), 0, st, src, src_stride, dst, dog,
-                           pyr_stride, dog_stride, w, h, t, tiles_x, tiles_y, ntiles, zero_row);
+    hipLaunchKernelGGL((k_blur_level<FR>), dim3(blocks), dim3(256), 0, st, src, src_stride, dst, pyr_stride, w, h, t,
+                       tiles_x, tiles_y, ntiles, zero_row);
 }
 
-int launch_blur(int fr, const float* src, size_t src_stride, float* dst, float* dog, size_t pyr_stride,
-                size_t dog_stride, int w, int h, int nframes, const Taps& t, const float* zero_row, hipStream_t st)
+int launch_blur(int fr, const float* src, size_t src_stride, float* dst, size_t pyr_stride, int w, int h, int nframes,
+                const Taps& t, const float* zero_row, hipStream_t st)
 {
     switch (fr) {
-    case 5: launch_blur_fr<5>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, zero_row, st); break;
-    case 6: launch_blur_fr<6>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, zero_row, st); break;
-    case 7: launch_blur_fr<7>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, zero_row, st); break;
-    case 9: launch_blur_fr<9>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, zero_row, st); break;
-    case 11: launch_blur_fr<11>(src, src_stride, dst, dog, pyr_stride, dog_stride, w, h, nframes, t, zero_row, st); break;
+    case 5: launch_blur_fr<5>(src, src_stride, dst, pyr_stride, w, h, nframes, t, zero_row, st); break;
+    case 6: launch_blur_fr<6>(src, src_stride, dst, pyr_stride, w, h, nframes, t, zero_row, st); break;
+    case 7: launch_blur_fr<7>(src, src_stride, dst, pyr_stride, w, h, nframes, t, zero_row, st); break;
+    case 9: launch_blur_fr<9>(src, src_stride, dst, pyr_stride, w, h, nframes, t, zero_row, st); break;
+    case 11: launch_blur_fr<11>(src, src_stride, dst, pyr_stride, w, h, nframes, t, zero_row, st); break;
     default:
         mif::set_error("no blur kernel for tap radius %d", fr);
         return MIF_ERR_UNSUPPORTED;
@@ -1306,7 +1301,7 @@ int enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes, bool split =
         if (items == 0) continue;
         hipStream_t run = (split && o > 0) ? s->aux[o] : s->stream;
         if (split && o > 0 && last_l3 >= 0) MIF_HIP(hipStreamWaitEvent(run, s->ev_l3[last_l3], 0));
-        const size_t pyr_stride = O.items * kLevels, dog_stride = O.items * (kLevels - 1);
+        const size_t pyr_stride = O.items * kLevels;
         if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][0], st));
         if (o == 0) {
             if (s->up) {
@@ -1337,14 +1332,13 @@ int enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes, bool split =
         }
         if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][1], st));
         // level 0 blurs the base image with sigma 1.6; level l >= 1 blurs level l-1
-        // (sift.cpp:1196-1218) and yields DoG[l-1] = level l - level l-1 (sift.cpp:256-260)
+        // (sift.cpp:1196-1218); DoG[l-1] = level l - level l-1 (sift.cpp:256-260) is formed by its readers
         for (int l = 0; l < kLevels; l++) {
             const float* src = (l == 0) ? O.base : O.pyr + (size_t)(l - 1) * items;
             const size_t src_stride = (l == 0) ? O.items : pyr_stride;
             float* dst = O.pyr + (size_t)l * items;
-            float* dog = (l == 0) ? nullptr : O.dog + (size_t)(l - 1) * items;
-            const int rc = launch_blur(s->fr[l], src, src_stride, dst, dog, pyr_stride, dog_stride, O.w, O.h, nf,
-                                       s->ktaps[l], s->zero_row, run);
+            const int rc = launch_blur(s->fr[l], src, src_stride, dst, pyr_stride, O.w, O.h, nf, s->ktaps[l],
+                                       s->zero_row, run);
             if (rc != MIF_OK) return rc;
             if (split && l == kIntervals) {             // level 3 feeds the next octave
                 MIF_HIP(hipEventRecord(s->ev_l3[o], run));
@@ -1385,7 +1379,7 @@ int enqueue_features(mif_sift* s, int want_desc)
         OctaveBuf& O = s->oct[o];
         if (O.items == 0) continue;
         hipStream_t so = (side_by_side && o > 0) ? s->aux[o] : st;
-        const size_t pyr_stride = O.items * kLevels, dog_stride = O.items * (kLevels - 1);
+        const size_t pyr_stride = O.items * kLevels;
         const size_t grad_stride = O.items * kIntervals;
         if (tm) MIF_HIP(hipEventRecord(s->ev_feat[o][0], st));
         MIF_HIP(hipMemsetAsync(O.rowcnt, 0, (size_t)nf * O.rows * sizeof(int), so));
@@ -1393,8 +1387,8 @@ int enqueue_features(mif_sift* s, int want_desc)
         {
             const int nbx = (O.w + 4 * kDetCols - 1) / (4 * kDetCols), nby = (O.h + kDetRows - 1) / kDetRows;
             const int nblocks = nbx * nby * nf;
-            hipLaunchKernelGGL(k_detect, dim3(8 * ((nblocks + 7) / 8)), dim3(256), 0, so, (const float*)O.dog,
-                               dog_stride, O.mask, O.rowcnt, O.w, O.h, O.words, o, nbx, nby, nblocks);
+            hipLaunchKernelGGL(k_detect, dim3(8 * ((nblocks + 7) / 8)), dim3(256), 0, so, (const float*)O.pyr,
+                               pyr_stride, O.mask, O.rowcnt, O.w, O.h, O.words, o, nbx, nby, nblocks);
         }
         const bool grad_first = side_by_side && want_desc && O.maxf > 0;
         if (grad_first)                         // independent of the detector: ahead of the wait below
@@ -1406,7 +1400,7 @@ int enqueue_features(mif_sift* s, int want_desc)
         if (side_by_side) MIF_HIP(hipEventRecord(s->ev_scan[o], so));
         last_scanned = o;
         if (O.maxf > 0) {
-            hipLaunchKernelGGL(k_emit, dim3((O.maxf + 255) / 256, nf), dim3(256), 0, so, (const float*)O.dog, dog_stride,
+            hipLaunchKernelGGL(k_emit, dim3((O.maxf + 255) / 256, nf), dim3(256), 0, so, (const float*)O.pyr, pyr_stride,
                                (const unsigned long long*)O.mask, (const int*)O.rowcnt, (const int*)O.rowoff, O.w,
                                O.h, O.words, o, O.maxf, s->cap, (const int*)s->counts, s->kp);
             if (tm) MIF_HIP(hipEventRecord(s->ev_feat[o][1], st));
@@ -1455,7 +1449,7 @@ void free_all(mif_sift* s)
 {
     for (int o = 0; o < kOctaves; o++) {
         OctaveBuf& O = s->oct[o];
-        (void)hipFree(O.base); (void)hipFree(O.pyr); (void)hipFree(O.dog); (void)hipFree(O.grad);
+        (void)hipFree(O.base); (void)hipFree(O.pyr); (void)hipFree(O.grad);
         (void)hipFree(O.mask); (void)hipFree(O.rowcnt); (void)hipFree(O.rowoff);
     }
     (void)hipFree(s->d_pixels); (void)hipFree(s->kp); (void)hipFree(s->orient);
@@ -1513,7 +1507,6 @@ int create_impl(mif_sift* s)
         if (O.items == 0) continue;
         MIF_HIP(hipMalloc(&O.base, B * O.items * sizeof(float)));
         MIF_HIP(hipMalloc(&O.pyr, B * O.items * kLevels * sizeof(float)));
-        MIF_HIP(hipMalloc(&O.dog, B * O.items * (kLevels - 1) * sizeof(float)));
         MIF_HIP(hipMalloc(&O.grad, B * O.items * kIntervals * sizeof(float2)));
         MIF_HIP(hipMalloc(&O.mask, B * O.rows * O.words * sizeof(unsigned long long)));
         MIF_HIP(hipMalloc(&O.rowcnt, B * O.rows * sizeof(int)));
@@ -1811,9 +1804,15 @@ int mif_sift_copy_dog(mif_sift* s, int frame, int octave, int index, float* out)
     mif::DeviceGuard guard(s->device);
     const OctaveBuf& O = s->oct[octave];
     MIF_HIP(hipStreamSynchronize(s->stream));
-    if (O.items)
-        MIF_HIP(hipMemcpy(out, O.dog + ((size_t)frame * (kLevels - 1) + index) * O.items, O.items * sizeof(float),
-                          hipMemcpyDeviceToHost));
+    if (O.items) {
+        // the DoG images are not stored: two levels are fetched and subtracted here (one IEEE float
+        // subtraction per pixel, kDiff of sift.cpp:256-260, as the detector does on the device)
+        std::vector<float> lower(O.items);
+        const float* base = O.pyr + ((size_t)frame * kLevels + index) * O.items;
+        MIF_HIP(hipMemcpy(lower.data(), base, O.items * sizeof(float), hipMemcpyDeviceToHost));
+        MIF_HIP(hipMemcpy(out, base + O.items, O.items * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < O.items; i++) out[i] = out[i] - lower[i];
+    }
     return MIF_OK;
 }
 
