@@ -504,9 +504,9 @@ __device__ bool refine_pixel(const float* __restrict__ pyr, size_t items, int w,
     return finish_pixel(r, cur, tx, ty, ts, o, out);
 }
 
-// Detection pass (sift.cpp:276-322, then the refinement), streaming form
-// without a staging tile. A wave owns a strip of 62 columns (lanes 1..62; lanes
-// 0 and 63 only carry the neighbouring columns) and walks kDetRows rows of it.
+// Detection pass (sift.cpp:276-322), streaming form without a staging tile. A
+// wave owns a strip of 62 columns (lanes 1..62; lanes 0 and 63 only carry the
+// neighbouring columns) and walks kDetRows rows of it.
 // Per row it loads one value per pyramid level and lane (six coalesced 256-byte
 // loads, issued a group of rows ahead), forms the five DoG values (level l+1 -
 // level l, kDiff of sift.cpp:256-260), obtains the left / right neighbours
@@ -515,21 +515,18 @@ __device__ bool refine_pixel(const float* __restrict__ pyr, size_t items, int w,
 // border, |D| > 0.0108333, and "v > every neighbour" evaluated as
 // v > max(neighbours) -- maxP leaves out (y-1, x+1), the position the
 // reference's test of the previous image never looks at (sift.cpp:299-301),
-// maxC leaves out the centre, max9 takes all nine; likewise for minima. The
-// few survivors are queued in LDS and refined one per thread; accepted
-// positions set their bit in the acceptance bitmask (cleared beforehand) and
-// bump the row total, both with integer atomics (order independent).
+// maxC leaves out the centre, max9 takes all nine; likewise for minima.
+// The survivors set their bit in the candidate bitmask (cleared beforehand)
+// with an integer atomic (order independent). The refinement, which needs many
+// more registers than this loop, is a kernel of its own (k_refine).
 constexpr int kDetCols = 62;        // output columns per wave
 constexpr int kDetRows = 32;        // rows per block
-constexpr int kDetGroup = 4;        // rows loaded ahead
-constexpr int kDetQueue = 4096;
+constexpr int kDetGroup = 3;        // rows loaded ahead
 
 __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ pyr, size_t pyr_stride,
-                                                unsigned long long* __restrict__ mask, int* __restrict__ rowcnt,
-                                                int w, int h, int words, int o, int nbx, int nby, int nblocks)
+                                                unsigned long long* __restrict__ cmask, int w, int h, int words,
+                                                int nbx, int nby, int nblocks)
 {
-    __shared__ int s_queue[kDetQueue];
-    __shared__ int s_ncand;
     const int item = xcd_contiguous_item(nblocks);
     if (item < 0) return;                        // uniform over the block
     const int f = item / (nbx * nby);
@@ -541,8 +538,7 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ pyr, s
     const int y0 = by * kDetRows;
     const size_t items = (size_t)w * h;
     pyr += (size_t)f * pyr_stride;
-    if (threadIdx.x == 0) s_ncand = 0;
-    __syncthreads();
+    cmask += (size_t)f * kIntervals * h * words;
     const bool xin = x >= 0 && x < w;
     const bool xtest = lane >= 1 && lane <= kDetCols && x > kBorder && x < w - kBorder;
     // one row of the six pyramid levels; the five DoG values are formed when the row enters the window
@@ -586,33 +582,7 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ pyr, s
         load_row(y0, v);
         push_row(v);
     }
-    // Rows are handled in groups; between groups the block drains the candidate
-    // queue when the next group could overflow it (a group adds at most
-    // kDetGroup x 4 x kDetCols x 3 entries) and once more at the end.
-    constexpr int kDrainAt = kDetQueue - kDetGroup * 4 * kDetCols * kIntervals;
-    static_assert(kDrainAt > 0, "candidate queue too small for one group of rows");
-    for (int g0 = 0;; g0 += kDetGroup) {
-        const bool done = g0 >= kDetRows || y0 + g0 >= h;      // uniform over the block
-        __syncthreads();
-        const int ncand = s_ncand;
-        if (done || ncand > kDrainAt) {
-            for (int q = threadIdx.x; q < ncand; q += 256) {
-                const int e = s_queue[q];
-                const int s = e >> 28;
-                const int y = y0 + ((e >> 16) & 0xfff);
-                const int cx = (e & 0xffff) - 1 + bx * 4 * kDetCols;
-                float4 kp;
-                if (refine_pixel(pyr, items, w, h, s, o, cx, y, &kp)) {
-                    const size_t r = (size_t)f * kIntervals * h + (s - 1) * h + y;
-                    atomicOr(&mask[r * words + (cx >> 6)], 1ull << (cx & 63));
-                    atomicAdd(&rowcnt[r], 1);
-                }
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) s_ncand = 0;
-            __syncthreads();
-        }
-        if (done) break;
+    for (int g0 = 0; g0 < kDetRows && y0 + g0 < h; g0 += kDetGroup) {      // uniform over the block
         float ahead[kDetGroup][kLevels];
 #pragma unroll
         for (int g = 0; g < kDetGroup; g++) load_row(y0 + g0 + g + 1, ahead[g]);
@@ -620,6 +590,7 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ pyr, s
         for (int g = 0; g < kDetGroup; g++) {
             const int y = y0 + g0 + g;
             push_row(ahead[g]);                             // window now centred on row y
+            if (g0 + g >= kDetRows) continue;               // the last group may reach past the block's rows
             float maxP[3], minP[3], maxC[3], minC[3], max9[3], min9[3], cen[3];
 #pragma unroll
             for (int l = 0; l < kLevels - 1; l++) {
@@ -648,12 +619,43 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ pyr, s
                 const bool cand = inside && (double)mif_fabsf(cur) > K_CONTR_THR_1 &&
                                   ((cur > maxP[s - 1] && cur > maxC[s - 1] && cur > max9[s - 1]) ||
                                    (cur < minP[s - 1] && cur < minC[s - 1] && cur < min9[s - 1]));
-                if (cand)
-                    s_queue[atomicAdd(&s_ncand, 1)] =
-                        (s << 28) | ((y - y0) << 16) | (x - bx * 4 * kDetCols + 1);
+                if (cand)                                               // about one lane in a hundred
+                    atomicOr(&cmask[((size_t)(s - 1) * h + y) * words + (x >> 6)], 1ull << (x & 63));
             }
         }
     }
+}
+
+// Refinement of the candidates (sift.cpp:323-417): one thread per 64-bit word of the candidate
+// bitmask. The thread refines every candidate of its word, writes the word of the acceptance
+// bitmask (all words, so that mask needs no clearing) and adds the accepted ones to the row total.
+__global__ __launch_bounds__(256) void k_refine(const float* __restrict__ pyr, size_t pyr_stride,
+                                                const unsigned long long* __restrict__ cmask,
+                                                unsigned long long* __restrict__ mask, int* __restrict__ rowcnt,
+                                                int w, int h, int words, int o, int nwords_total)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;    // word index over (frame, level, row, word)
+    if (i >= nwords_total) return;
+    unsigned long long c = cmask[i];
+    unsigned long long acc = 0ull;
+    if (c != 0ull) {
+        const int r_all = i / words;                        // (frame * 3 + level) * h + y
+        const int k = i - r_all * words;
+        const int fl = r_all / h;
+        const int y = r_all - fl * h;
+        const int f = fl / kIntervals;
+        const int s = fl - f * kIntervals + 1;
+        const float* P = pyr + (size_t)f * pyr_stride;
+        const size_t items = (size_t)w * h;
+        while (c != 0ull) {
+            const int bit = __ffsll((long long)c) - 1;
+            c &= c - 1ull;
+            float4 kp;
+            if (refine_pixel(P, items, w, h, s, o, k * 64 + bit, y, &kp)) acc |= 1ull << bit;
+        }
+        if (acc != 0ull) atomicAdd(&rowcnt[r_all], __popcll(acc));
+    }
+    mask[i] = acc;
 }
 
 // Exclusive scan of a frame's per-row counts (rows ordered level-major, then
@@ -1143,7 +1145,8 @@ struct OctaveBuf {
     float* base = nullptr;                 // [h][w] input of level 0
     float* pyr = nullptr;                  // [6][h][w]
     float2* grad = nullptr;                // [3][h][w] gradient {mag, theta} of levels 1..3
-    unsigned long long* mask = nullptr;    // [3*h][words]
+    unsigned long long* mask = nullptr;    // [3*h][words] accepted positions
+    unsigned long long* cmask = nullptr;   // [3*h][words] candidates (extrema above the contrast pre-test)
     int* rowcnt = nullptr;                 // [3*h]
     int* rowoff = nullptr;                 // [3*h]
 };
@@ -1383,12 +1386,15 @@ int enqueue_features(mif_sift* s, int want_desc)
         const size_t grad_stride = O.items * kIntervals;
         if (tm) MIF_HIP(hipEventRecord(s->ev_feat[o][0], st));
         MIF_HIP(hipMemsetAsync(O.rowcnt, 0, (size_t)nf * O.rows * sizeof(int), so));
-        MIF_HIP(hipMemsetAsync(O.mask, 0, (size_t)nf * O.rows * O.words * sizeof(unsigned long long), so));
+        MIF_HIP(hipMemsetAsync(O.cmask, 0, (size_t)nf * O.rows * O.words * sizeof(unsigned long long), so));
         {
             const int nbx = (O.w + 4 * kDetCols - 1) / (4 * kDetCols), nby = (O.h + kDetRows - 1) / kDetRows;
             const int nblocks = nbx * nby * nf;
             hipLaunchKernelGGL(k_detect, dim3(8 * ((nblocks + 7) / 8)), dim3(256), 0, so, (const float*)O.pyr,
-                               pyr_stride, O.mask, O.rowcnt, O.w, O.h, O.words, o, nbx, nby, nblocks);
+                               pyr_stride, O.cmask, O.w, O.h, O.words, nbx, nby, nblocks);
+            const int nwords = nf * O.rows * O.words;
+            hipLaunchKernelGGL(k_refine, dim3((nwords + 255) / 256), dim3(256), 0, so, (const float*)O.pyr, pyr_stride,
+                               (const unsigned long long*)O.cmask, O.mask, O.rowcnt, O.w, O.h, O.words, o, nwords);
         }
         const bool grad_first = side_by_side && want_desc && O.maxf > 0;
         if (grad_first)                         // independent of the detector: ahead of the wait below
@@ -1450,7 +1456,7 @@ void free_all(mif_sift* s)
     for (int o = 0; o < kOctaves; o++) {
         OctaveBuf& O = s->oct[o];
         (void)hipFree(O.base); (void)hipFree(O.pyr); (void)hipFree(O.grad);
-        (void)hipFree(O.mask); (void)hipFree(O.rowcnt); (void)hipFree(O.rowoff);
+        (void)hipFree(O.mask); (void)hipFree(O.cmask); (void)hipFree(O.rowcnt); (void)hipFree(O.rowoff);
     }
     (void)hipFree(s->d_pixels); (void)hipFree(s->kp); (void)hipFree(s->orient);
     (void)hipFree(s->desc); (void)hipFree(s->counts); (void)hipFree(s->zero_row);
@@ -1509,6 +1515,7 @@ int create_impl(mif_sift* s)
         MIF_HIP(hipMalloc(&O.pyr, B * O.items * kLevels * sizeof(float)));
         MIF_HIP(hipMalloc(&O.grad, B * O.items * kIntervals * sizeof(float2)));
         MIF_HIP(hipMalloc(&O.mask, B * O.rows * O.words * sizeof(unsigned long long)));
+        MIF_HIP(hipMalloc(&O.cmask, B * O.rows * O.words * sizeof(unsigned long long)));
         MIF_HIP(hipMalloc(&O.rowcnt, B * O.rows * sizeof(int)));
         MIF_HIP(hipMalloc(&O.rowoff, B * O.rows * sizeof(int)));
     }
