@@ -26,11 +26,12 @@ constexpr int kQT = 32;      // query rows per wave (one 32x32 MFMA tile)
 constexpr int kWaves = 4;    // waves per block, each with its own query tile
 constexpr int kDC = 64;      // database rows per staged chunk (two MFMA tiles)
 constexpr float kInf = __builtin_inff();
-constexpr int kMaxPairs = 32;   // pairs per launch (the table travels as a kernel argument)
+constexpr int kMaxPairs = 256;  // pairs per launch (their item ranges are cached in LDS)
+constexpr int kTableSlots = 4;  // pair tables in flight per matcher
 
-struct PairTable {
-    mif_match_pair p[kMaxPairs];
-};
+// The pair table of a call lives in device memory (copied there on the call's stream), so that
+// one launch can serve a whole batch of frame pairs: few launches mean few tails.
+typedef const mif_match_pair* __restrict__ PairTable;
 
 // Loads `n` (<= 32) consecutive floats of a row into registers with as few
 // round trips to memory as possible: 16-byte loads when the row allows it.
@@ -56,7 +57,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void k_row_norms(PairTable tbl, int which, int n_cap, int dim, int ld,
                                                    float* __restrict__ out)
 {
-    const mif_match_pair& pr = tbl.p[blockIdx.y];
+    const mif_match_pair& pr = tbl[blockIdx.y];
     const float* __restrict__ m = which ? pr.d_db : pr.d_q;
     const int* d_n = which ? pr.d_nd : pr.d_nq;
     out += (size_t)blockIdx.y * n_cap;
@@ -144,11 +145,12 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int npairs
     const int half = lane >> 5;
     const int col = lane & 31;
 
-    if (tid == 0) {
-        int total = 0;
-        for (int z = 0; z < npairs; z++) {
-            s_first[z] = total;
-            const mif_match_pair& pz = tbl.p[z];
+    // Items of every pair (one thread per pair), then their exclusive prefix sums by the first wave:
+    // s_first[z] = first item of pair z; pairs beyond npairs count nothing, s_first[kMaxPairs] = total.
+    for (int z = tid; z < kMaxPairs; z += 256) {
+        int cnt = 0;
+        if (z < npairs) {
+            const mif_match_pair& pz = tbl[z];
             const int nqz = pz.d_nq ? min(*pz.d_nq, nq_cap) : nq_cap;
             const int ndz = pz.d_nd ? min(*pz.d_nd, nd_cap) : nd_cap;
             s_rows[z][0] = nqz;
@@ -156,10 +158,27 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int npairs
             const int chunks = (ndz + kDC - 1) / kDC;
             const int per = (chunks + nsplit - 1) / nsplit;
             const int live = per > 0 ? (chunks + per - 1) / per : 0;         // splits that hold rows
-            total += ((nqz + kQT * kWaves - 1) / (kQT * kWaves)) * live;
+            cnt = ((nqz + kQT * kWaves - 1) / (kQT * kWaves)) * live;
         }
-        s_first[npairs] = total;
-        s_item = (int)atomicAdd(work_counter, 1u);
+        s_first[z + 1] = cnt;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        constexpr int PER = kMaxPairs / 64;
+        int c[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { c[j] = s_first[tid * PER + j + 1]; sum += c[j]; }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (tid >= d) incl += o;
+        }
+        int run = incl - sum;
+        if (tid == 0) s_first[0] = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { run += c[j]; s_first[tid * PER + j + 1] = run; }
+        if (tid == 0) s_item = (int)atomicAdd(work_counter, 1u);
     }
 
     // staging coordinates of this thread: float4 column k4 of rows r0, r0 + RSTEP, ...
@@ -174,15 +193,23 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int npairs
     __syncthreads();                           // s_item is set; the previous item is done with LDS
     const int item = __builtin_amdgcn_readfirstlane(s_item);
     __syncthreads();                           // every thread has read it
-    if (item >= s_first[npairs]) break;        // uniform over the block
+    if (item >= s_first[kMaxPairs]) break;     // uniform over the block
     // the item after this one is drawn now and published when this one is finished, so the
     // latency of the counter is covered by the work
     int next_item = 0;
     if (tid == 0) next_item = (int)atomicAdd(work_counter, 1u);
+    // the pair that owns the item: the last z with s_first[z] <= item (empty pairs share their
+    // first item with the next pair, so the last one among equals is the owner)
     int z = 0;
-    while (item >= s_first[z + 1]) z++;
+    {
+        int hi = npairs - 1;
+        while (z < hi) {
+            const int mid = (z + hi + 1) >> 1;
+            if (s_first[mid] <= item) z = mid; else hi = mid - 1;
+        }
+    }
     z = __builtin_amdgcn_readfirstlane(z);
-    const mif_match_pair& pr = tbl.p[z];
+    const mif_match_pair& pr = tbl[z];
     const float* __restrict__ Q = pr.d_q;
     const float* __restrict__ D = pr.d_db;
     const float* __restrict__ qn = qn_all + (size_t)z * nq_cap;
@@ -372,7 +399,7 @@ __global__ __launch_bounds__(128) void k_match_finalize(PairTable tbl, int nq_ca
                                                         int nsplit, const float* __restrict__ part_s,
                                                         const int* __restrict__ part_i)
 {
-    const mif_match_pair& pr = tbl.p[blockIdx.y];
+    const mif_match_pair& pr = tbl[blockIdx.y];
     const float* __restrict__ Q = pr.d_q;
     const float* __restrict__ D = pr.d_db;
     const int* d_nq = pr.d_nq;
@@ -444,7 +471,7 @@ __global__ __launch_bounds__(256) void k_match_filter(PairTable tbl, int nq_cap,
 {
     __shared__ double s_min[256], s_max[256];
     __shared__ int s_cnt[256];
-    const mif_match_pair& pr = tbl.p[blockIdx.x];
+    const mif_match_pair& pr = tbl[blockIdx.x];
     if (!pr.d_good || !pr.d_summary) return;
     const int nq = pr.d_nq ? min(*pr.d_nq, nq_cap) : nq_cap;
     const float* __restrict__ dist2 = pr.d_dist2;
@@ -506,6 +533,13 @@ struct mif_matcher {
     float* d_dist = nullptr;
     float* d_score = nullptr;
     unsigned int* work = nullptr;   // work-item counter of k_match_partial
+    // pair tables: pinned host copies and their device twins, used in rotation; a slot is reused
+    // once the call that read it last has finished on the GPU (slot_ev)
+    mif_match_pair* h_tbl[kTableSlots] = {};
+    mif_match_pair* d_tbl[kTableSlots] = {};
+    hipEvent_t slot_ev[kTableSlots] = {};
+    bool slot_used[kTableSlots] = {};
+    int next_slot = 0;
     int blocks = 512;               // persistent blocks: two per compute unit
 };
 
@@ -518,6 +552,11 @@ void free_matcher(mif_matcher* m)
     (void)hipFree(m->qn); (void)hipFree(m->dn); (void)hipFree(m->part_s); (void)hipFree(m->part_i);
     (void)hipFree(m->d_q); (void)hipFree(m->d_db); (void)hipFree(m->d_idx); (void)hipFree(m->d_dist);
     (void)hipFree(m->d_score); (void)hipFree(m->work);
+    for (int i = 0; i < kTableSlots; i++) {
+        if (m->h_tbl[i]) (void)hipHostFree(m->h_tbl[i]);
+        (void)hipFree(m->d_tbl[i]);
+        if (m->slot_ev[i]) (void)hipEventDestroy(m->slot_ev[i]);
+    }
 }
 
 int pick_split(int nq, int nd, int npairs, bool device_counts)
@@ -558,29 +597,36 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
         return MIF_ERR_INVALID_ARGUMENT;
     }
     if (nq == 0 || npairs == 0) return MIF_OK;
+    for (int i = 0; i < npairs; i++) {
+        if (!pairs[i].d_q || !pairs[i].d_idx2 || !pairs[i].d_dist2 || (nd > 0 && !pairs[i].d_db)) {
+            mif::set_error("match: pair %d has a NULL pointer", i);
+            return MIF_ERR_INVALID_ARGUMENT;
+        }
+    }
+    // the call's pair table goes to the device through the next slot of the rotation
+    const int slot = m->next_slot;
+    m->next_slot = (slot + 1) % kTableSlots;
+    if (m->slot_used[slot]) MIF_HIP(hipEventSynchronize(m->slot_ev[slot]));
+    memcpy(m->h_tbl[slot], pairs, (size_t)npairs * sizeof(mif_match_pair));
+    MIF_HIP(hipMemcpyAsync(m->d_tbl[slot], m->h_tbl[slot], (size_t)npairs * sizeof(mif_match_pair),
+                           hipMemcpyHostToDevice, st));
+    m->slot_used[slot] = true;
     for (int base = 0; base < npairs; base += kMaxPairs) {
         const int np = std::min(kMaxPairs, npairs - base);
-        PairTable tbl;
-        memset(&tbl, 0, sizeof(tbl));
-        for (int i = 0; i < np; i++) {
-            tbl.p[i] = pairs[base + i];
-            if (!tbl.p[i].d_q || !tbl.p[i].d_idx2 || !tbl.p[i].d_dist2 || (nd > 0 && !tbl.p[i].d_db)) {
-                mif::set_error("match: pair %d has a NULL pointer", base + i);
-                return MIF_ERR_INVALID_ARGUMENT;
-            }
-        }
+        const mif_match_pair* hp = pairs + base;
+        const mif_match_pair* tbl = m->d_tbl[slot] + base;
         float* qn = m->qn + (size_t)base * m->max_q;
         float* dn = m->dn + (size_t)base * m->max_d;
         float* ps = m->part_s + (size_t)base * kMaxSplit * m->max_q * 2;
         int* pi = m->part_i + (size_t)base * kMaxSplit * m->max_q * 2;
         bool device_counts = false;
-        for (int i = 0; i < np; i++) device_counts = device_counts || tbl.p[i].d_nq || tbl.p[i].d_nd;
+        for (int i = 0; i < np; i++) device_counts = device_counts || hp[i].d_nq || hp[i].d_nd;
         const int nsplit = pick_split(nq, nd, np, device_counts);
         // 16-byte loads of rows need ld % 4 == 0 and 16-byte aligned row starts
         bool vec_db = (ld % 4) == 0, vec_q = (ld % 4) == 0;
         for (int i = 0; i < np; i++) {
-            vec_db = vec_db && ((reinterpret_cast<uintptr_t>(tbl.p[i].d_db) & 15u) == 0);
-            vec_q = vec_q && ((reinterpret_cast<uintptr_t>(tbl.p[i].d_q) & 15u) == 0);
+            vec_db = vec_db && ((reinterpret_cast<uintptr_t>(hp[i].d_db) & 15u) == 0);
+            vec_q = vec_q && ((reinterpret_cast<uintptr_t>(hp[i].d_q) & 15u) == 0);
         }
         if (nd > 0) {
             if (vec_db)
@@ -610,6 +656,7 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
             hipLaunchKernelGGL(k_match_filter, dim3(np), dim3(256), 0, st, tbl, nq, filter_mode);
     }
     MIF_HIP(hipGetLastError());
+    MIF_HIP(hipEventRecord(m->slot_ev[slot], st));
     return MIF_OK;
 }
 
@@ -642,6 +689,11 @@ int mif_match_create_batched(int device, int max_query, int max_database, int ma
     if ((e = hipMalloc(&m->part_s, P * kMaxSplit * max_query * 2 * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->part_i, P * kMaxSplit * max_query * 2 * sizeof(int))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->work, sizeof(unsigned int))) != hipSuccess) return fail(e);
+    for (int i = 0; i < kTableSlots; i++) {
+        if ((e = hipHostMalloc(&m->h_tbl[i], P * sizeof(mif_match_pair))) != hipSuccess) return fail(e);
+        if ((e = hipMalloc(&m->d_tbl[i], P * sizeof(mif_match_pair))) != hipSuccess) return fail(e);
+        if ((e = hipEventCreateWithFlags(&m->slot_ev[i], hipEventDisableTiming)) != hipSuccess) return fail(e);
+    }
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
         m->blocks = 2 * cus;

@@ -523,9 +523,11 @@ constexpr int kDetCols = 62;        // output columns per wave
 constexpr int kDetRows = 32;        // rows per block
 constexpr int kDetGroup = 3;        // rows loaded ahead
 
+template <bool GRAD>
 __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ pyr, size_t pyr_stride,
                                                 unsigned long long* __restrict__ cmask, int w, int h, int words,
-                                                int nbx, int nby, int nblocks)
+                                                int nbx, int nby, int nblocks, float2* __restrict__ grad,
+                                                size_t grad_stride)
 {
     const int item = xcd_contiguous_item(nblocks);
     if (item < 0) return;                        // uniform over the block
@@ -539,7 +541,9 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ pyr, s
     const size_t items = (size_t)w * h;
     pyr += (size_t)f * pyr_stride;
     cmask += (size_t)f * kIntervals * h * words;
+    if (GRAD) grad += (size_t)f * grad_stride;
     const bool xin = x >= 0 && x < w;
+    const bool xgrad = lane >= 1 && lane <= kDetCols && x >= 1 && x <= w - 2;
     const bool xtest = lane >= 1 && lane <= kDetCols && x > kBorder && x < w - kBorder;
     // one row of the six pyramid levels; the five DoG values are formed when the row enters the window
     auto load_row = [&](int y, float v[kLevels]) {
@@ -549,7 +553,17 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ pyr, s
     };
     // nb[l][r][c]: rows r = 0..2 <-> y-1, y, y+1; columns c = 0..2 <-> x-1, x, x+1
     float nb[kLevels - 1][3][3];
+    // GRAD: levels 1..3 of this lane's column at rows y-1, y, y+1
+    float raw[kIntervals][3];
     auto push_row = [&](const float lv[kLevels]) {
+        if (GRAD) {
+#pragma unroll
+            for (int l = 0; l < kIntervals; l++) {
+                raw[l][0] = raw[l][1];
+                raw[l][1] = raw[l][2];
+                raw[l][2] = lv[l + 1];
+            }
+        }
         float v[kLevels - 1];
 #pragma unroll
         for (int l = 0; l < kLevels - 1; l++) v[l] = lv[l + 1] - lv[l];      // kDiff, sift.cpp:256-260
@@ -577,6 +591,10 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ pyr, s
             for (int r = 0; r < 3; r++)
 #pragma unroll
                 for (int c = 0; c < 3; c++) nb[l][r][c] = 0.0f;
+#pragma unroll
+        for (int l = 0; l < kIntervals; l++)
+#pragma unroll
+            for (int r = 0; r < 3; r++) raw[l][r] = 0.0f;
         load_row(y0 - 1, v);
         push_row(v);
         load_row(y0, v);
@@ -591,6 +609,24 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ pyr, s
             const int y = y0 + g0 + g;
             push_row(ahead[g]);                             // window now centred on row y
             if (g0 + g >= kDetRows) continue;               // the last group may reach past the block's rows
+            if (GRAD) {
+                // gradient planes of levels 1..3 at (x, y), see k_gradient: the same operations on the
+                // same operands, so the same bits
+                const bool gok = xgrad && y >= 1 && y <= h - 2;
+#pragma unroll
+                for (int l = 0; l < kIntervals; l++) {
+                    const int ci = __builtin_bit_cast(int, raw[l][1]);
+                    const float lf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, ci, 0x138, 0xf, 0xf, false));
+                    const float rt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, ci, 0x130, 0xf, 0xf, false));
+                    const float dx = rt - lf;
+                    const float dy = raw[l][0] - raw[l][2];
+                    const float mag = __builtin_sqrtf(dx * dx + dy * dy);
+                    const float theta = mif_atan2f(dy, dx);
+                    const uint32_t mb = (mif_float_to_bits(mag) & 0x7fffffffu) | (dy != 0.0f ? 0x80000000u : 0u);
+                    const v2f val = (v2f){mif_bits_to_float(mb), theta};
+                    if (gok) *(v2f*)&grad[(size_t)l * items + (size_t)y * w + x] = val;
+                }
+            }
             float maxP[3], minP[3], maxC[3], minC[3], max9[3], min9[3], cen[3];
 #pragma unroll
             for (int l = 0; l < kLevels - 1; l++) {
@@ -1384,19 +1420,25 @@ int enqueue_features(mif_sift* s, int want_desc)
         hipStream_t so = (side_by_side && o > 0) ? s->aux[o] : st;
         const size_t pyr_stride = O.items * kLevels;
         const size_t grad_stride = O.items * kIntervals;
+        static const bool no_fuse = getenv("MIF_NO_FUSED_GRAD") != nullptr;      // A/B switch
+        const bool fused_grad = want_desc && O.maxf > 0 && !no_fuse;
         if (tm) MIF_HIP(hipEventRecord(s->ev_feat[o][0], st));
         MIF_HIP(hipMemsetAsync(O.rowcnt, 0, (size_t)nf * O.rows * sizeof(int), so));
         MIF_HIP(hipMemsetAsync(O.cmask, 0, (size_t)nf * O.rows * O.words * sizeof(unsigned long long), so));
         {
             const int nbx = (O.w + 4 * kDetCols - 1) / (4 * kDetCols), nby = (O.h + kDetRows - 1) / kDetRows;
             const int nblocks = nbx * nby * nf;
-            hipLaunchKernelGGL(k_detect, dim3(8 * ((nblocks + 7) / 8)), dim3(256), 0, so, (const float*)O.pyr,
-                               pyr_stride, O.cmask, O.w, O.h, O.words, nbx, nby, nblocks);
+            if (fused_grad)
+                hipLaunchKernelGGL(k_detect<true>, dim3(8 * ((nblocks + 7) / 8)), dim3(256), 0, so, (const float*)O.pyr,
+                                   pyr_stride, O.cmask, O.w, O.h, O.words, nbx, nby, nblocks, O.grad, grad_stride);
+            else
+                hipLaunchKernelGGL(k_detect<false>, dim3(8 * ((nblocks + 7) / 8)), dim3(256), 0, so, (const float*)O.pyr,
+                                   pyr_stride, O.cmask, O.w, O.h, O.words, nbx, nby, nblocks, (float2*)nullptr, (size_t)0);
             const int nwords = nf * O.rows * O.words;
             hipLaunchKernelGGL(k_refine, dim3((nwords + 255) / 256), dim3(256), 0, so, (const float*)O.pyr, pyr_stride,
                                (const unsigned long long*)O.cmask, O.mask, O.rowcnt, O.w, O.h, O.words, o, nwords);
         }
-        const bool grad_first = side_by_side && want_desc && O.maxf > 0;
+        const bool grad_first = side_by_side && want_desc && O.maxf > 0 && !fused_grad;
         if (grad_first)                         // independent of the detector: ahead of the wait below
             hipLaunchKernelGGL(k_gradient, dim3((O.w + 127) / 128, (O.h + 2 * kGradRows - 1) / (2 * kGradRows), kIntervals * nf),
                                dim3(256), 0, so, (const float*)O.pyr, pyr_stride, O.grad, grad_stride, O.w, O.h);
@@ -1411,7 +1453,7 @@ int enqueue_features(mif_sift* s, int want_desc)
                                O.h, O.words, o, O.maxf, s->cap, (const int*)s->counts, s->kp);
             if (tm) MIF_HIP(hipEventRecord(s->ev_feat[o][1], st));
             if (want_desc) {
-                if (!grad_first)
+                if (!grad_first && !fused_grad)
                     hipLaunchKernelGGL(k_gradient, dim3((O.w + 127) / 128, (O.h + 2 * kGradRows - 1) / (2 * kGradRows), kIntervals * nf),
                                        dim3(256), 0, so,
                                        (const float*)O.pyr, pyr_stride, O.grad, grad_stride, O.w, O.h);

@@ -8,7 +8,7 @@ import object_detection_amd as oda
 from object_detection_amd import _lib
 from synth import sift_like_descriptors
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3221
-cap, B = int(os.environ.get('CAP', '27216')), 16
+cap, B = int(os.environ.get('CAP', '27216')), int(os.environ.get('PAIRS', '16'))
 DEVC = os.environ.get('DEVC', '1') == '1'
 dev = torch.device("cuda", 0)
 des = torch.zeros((B + 1, cap, 128), dtype=torch.float32, device=dev)
