@@ -222,8 +222,19 @@ __global__ void k_decimate(const float* __restrict__ src, size_t src_stride, flo
 // per XCD (consecutive blocks go to consecutive XCDs), so that neighbouring
 // tiles, which share halo rows and columns, meet in the same L2.
 
-template <int FR>
-__global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ src, size_t src_stride,
+// Where a blur launch takes its input from. Level 0 of an octave blurs the octave's base image;
+// that image is a pure function of the frame's pixels (octave 0) or of the previous octave's level
+// 3 (octaves 1, 2), so the level-0 launch forms it while staging its window and the base image is
+// never written to memory nor read back:
+//   kSrcFloat     a float image [h][w] (levels 1..5, and level 0 when the base image is stored)
+//   kSrcGrayU8    8-bit gray frame, value / 255 (sift.cpp:901-913)
+//   kSrcBgrU8     8-bit interleaved BGR frame, kColor_interleaved_ch (sift.cpp:55-72)
+//   kSrcDecimated previous octave's pyramid, kDown_pyramid (sift.cpp:113-132) with its flat
+//                 indexing: pixel (x, y) = prev[3*(2w)*(2h) + (2y)*(2w) + 2x]
+enum { kSrcFloat = 0, kSrcGrayU8 = 1, kSrcBgrU8 = 2, kSrcDecimated = 3 };
+
+template <int FR, int SRC>
+__global__ __launch_bounds__(256) void k_blur_level(const void* __restrict__ src_any, size_t src_stride,
                                                     float* __restrict__ dst, size_t pyr_stride, int w, int h,
                                                     Taps taps,
                                                     int tiles_x, int tiles_y, int ntiles,
@@ -258,7 +269,8 @@ __global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ sr
     const int rem = t - z * tiles_xy;
     const int ty = rem / tiles_x;
     const int x0 = (rem - ty * tiles_x) * TW, y0 = ty * TH;
-    src += (size_t)z * src_stride;
+    // src_stride counts elements of the source: floats, or bytes of an 8-bit frame
+    const char* const src = (const char*)src_any + (size_t)z * src_stride * ((SRC == kSrcFloat || SRC == kSrcDecimated) ? 4 : 1);
     dst += (size_t)z * pyr_stride;
 
     // stage the input window
@@ -267,28 +279,53 @@ __global__ __launch_bounds__(256) void k_blur_level(const float* __restrict__ sr
         const bool in0 = gx0 >= 0 && gx0 < w;
         const bool in1 = gx1 >= 0 && gx1 < w;
         // the second load covers the columns beyond 64; its idle lanes repeat the last one
-        const unsigned boff0 = 4u * (unsigned)min(max(gx0, 0), w - 1);
-        const unsigned boff1 = 4u * (unsigned)min(max(min(gx1, x0 - FR + EW - 1), 0), w - 1);
+        const int cx0 = min(max(gx0, 0), w - 1);
+        const int cx1 = min(max(min(gx1, x0 - FR + EW - 1), 0), w - 1);
+        // byte offset of a lane's pixel within its row, and the row pitch in bytes. A BGR pixel is
+        // fetched as one (unaligned) 32-bit word that starts at its B byte, or one byte earlier for
+        // the last pixel of a row so that the word ends with the row.
+        constexpr unsigned px_bytes = SRC == kSrcFloat ? 4u : SRC == kSrcGrayU8 ? 1u : SRC == kSrcBgrU8 ? 3u : 8u;
+        const unsigned row_bytes = (SRC == kSrcDecimated ? 4u * 4u : px_bytes) * (unsigned)w;
+        const unsigned lim = 3u * (unsigned)w - 4u;
+        const unsigned boff0 = (SRC == kSrcBgrU8) ? min(px_bytes * (unsigned)cx0, lim) : px_bytes * (unsigned)cx0;
+        const unsigned boff1 = (SRC == kSrcBgrU8) ? min(px_bytes * (unsigned)cx1, lim) : px_bytes * (unsigned)cx1;
+        const unsigned sh0 = 8u * (3u * (unsigned)cx0 - boff0), sh1 = 8u * (3u * (unsigned)cx1 - boff1);
+        const char* const img0 = src + (SRC == kSrcDecimated ? 4u * (unsigned)(kIntervals * w * 2 * h * 2) : 0u);
+        auto fetch = [&](const char* at) -> float {
+            if (SRC == kSrcFloat || SRC == kSrcDecimated) return *(const float*)at;
+            uint32_t v;
+            if (SRC == kSrcGrayU8) v = *(const uint8_t*)at;
+            else __builtin_memcpy(&v, at, 4);
+            return __builtin_bit_cast(float, v);
+        };
+        // raw word -> pixel value (the conversions of the reference, see the kernels of the same name)
+        auto value = [&](float raw, unsigned sh) -> float {
+            if (SRC == kSrcFloat || SRC == kSrcDecimated) return raw;
+            const uint32_t v = __builtin_bit_cast(uint32_t, raw);
+            if (SRC == kSrcGrayU8) return (float)v / 255.0f;
+            const uint32_t u = v >> sh;
+            return gray_of_bgr((float)(u & 255u), (float)((u >> 8) & 255u), (float)((u >> 16) & 255u));
+        };
         float st0[kSteps], st1[kSteps];
 #pragma unroll
         for (int it = 0; it < kSteps; it++) {
             const int gy = y0 - FR + wv + 4 * it;
             const int gyc = min(max(gy, 0), h - 1);
-            const float* inside = src + (unsigned)(gyc * w);
-            const char* rowp = (const char*)((gy == gyc) ? inside : zero_row);
-            st0[it] = *(const float*)(rowp + boff0);
-            st1[it] = *(const float*)(rowp + boff1);
+            const char* inside = img0 + (unsigned)gyc * row_bytes;
+            const char* rowp = (gy == gyc) ? inside : (const char*)zero_row;
+            st0[it] = fetch(rowp + boff0);
+            st1[it] = fetch(rowp + boff1);
         }
 #pragma unroll
         for (int it = 0; it < kSteps; it++) {
             const int ly = wv + 4 * it;
-            if (4 * it + 3 < EH || ly < EH) s_in[lane * PT + ly] = in0 ? st0[it] : 0.0f;
+            if (4 * it + 3 < EH || ly < EH) s_in[lane * PT + ly] = in0 ? value(st0[it], sh0) : 0.0f;
         }
         if (lane < EW - 64) {
 #pragma unroll
             for (int it = 0; it < kSteps; it++) {
                 const int ly = wv + 4 * it;
-                if (4 * it + 3 < EH || ly < EH) s_in[(64 + lane) * PT + ly] = in1 ? st1[it] : 0.0f;
+                if (4 * it + 3 < EH || ly < EH) s_in[(64 + lane) * PT + ly] = in1 ? value(st1[it], sh1) : 0.0f;
             }
         }
     }
@@ -1276,24 +1313,40 @@ struct mif_sift {
     hipStream_t aux[kOctaves] = {};          // [0] unused: octave 0 stays on `stream`
     hipEvent_t ev_fork = nullptr, ev_scan[kOctaves] = {}, ev_join[kOctaves] = {}, ev_l3[kOctaves] = {};
     bool pyramid_split = false;              // the scale spaces in the handle were built on the side streams
+    // the level-0 blur launches read the frames / the previous octave directly; base images are only
+    // written on request (mif_sift_copy_base), from the pixels of the last call
+    bool fused_base = false;
+    const void* last_pixels = nullptr;
 };
 
 namespace {
 
-template <int FR>
-void launch_blur_fr(const float* src, size_t src_stride, float* dst, size_t pyr_stride, int w, int h, int nframes,
+template <int FR, int SRC = kSrcFloat>
+void launch_blur_fr(const void* src, size_t src_stride, float* dst, size_t pyr_stride, int w, int h, int nframes,
                     const Taps& t, const float* zero_row, hipStream_t st)
 {
     const int tiles_x = (w + kBlurTile - 1) / kBlurTile, tiles_y = (h + kBlurTile - 1) / kBlurTile;
     const int ntiles = tiles_x * tiles_y * nframes;
     const int blocks = 8 * ((ntiles + 7) / 8);             // one equal share of the tiles per XCD
-    hipLaunchKernelGGL((k_blur_level<FR>), dim3(blocks), dim3(256), 0, st, src, src_stride, dst, pyr_stride, w, h, t,
-                       tiles_x, tiles_y, ntiles, zero_row);
+    hipLaunchKernelGGL((k_blur_level<FR, SRC>), dim3(blocks), dim3(256), 0, st, src, src_stride, dst, pyr_stride, w, h,
+                       t, tiles_x, tiles_y, ntiles, zero_row);
 }
 
-int launch_blur(int fr, const float* src, size_t src_stride, float* dst, size_t pyr_stride, int w, int h, int nframes,
-                const Taps& t, const float* zero_row, hipStream_t st)
+// Tap radius of level 0 (sigma 1.6): the only radius whose kernel exists for every source kind.
+constexpr int kBaseRadius = 6;
+
+int launch_blur(int fr, const void* src, size_t src_stride, float* dst, size_t pyr_stride, int w, int h, int nframes,
+                const Taps& t, const float* zero_row, hipStream_t st, int src_kind = kSrcFloat)
 {
+    if (src_kind != kSrcFloat) {
+        if (fr != kBaseRadius) { mif::set_error("no fused base-image blur for tap radius %d", fr); return MIF_ERR_UNSUPPORTED; }
+        switch (src_kind) {
+        case kSrcGrayU8: launch_blur_fr<kBaseRadius, kSrcGrayU8>(src, src_stride, dst, pyr_stride, w, h, nframes, t, zero_row, st); break;
+        case kSrcBgrU8: launch_blur_fr<kBaseRadius, kSrcBgrU8>(src, src_stride, dst, pyr_stride, w, h, nframes, t, zero_row, st); break;
+        default: launch_blur_fr<kBaseRadius, kSrcDecimated>(src, src_stride, dst, pyr_stride, w, h, nframes, t, zero_row, st); break;
+        }
+        return MIF_OK;
+    }
     switch (fr) {
     case 5: launch_blur_fr<5>(src, src_stride, dst, pyr_stride, w, h, nframes, t, zero_row, st); break;
     case 6: launch_blur_fr<6>(src, src_stride, dst, pyr_stride, w, h, nframes, t, zero_row, st); break;
@@ -1305,6 +1358,44 @@ int launch_blur(int fr, const float* src, size_t src_stride, float* dst, size_t 
         return MIF_ERR_UNSUPPORTED;
     }
     return MIF_OK;
+}
+
+// Writes the base image of octave o (the input of its level 0) for `nf` frames into O.base: the
+// gray conversion of the frames (octave 0) or the decimated level 3 of the previous octave.
+// `first` selects the frame of the batch to start from.
+void write_base(mif_sift* s, int o, const void* d_pixels, int first, int nf, hipStream_t run)
+{
+    OctaveBuf& O = s->oct[o];
+    const int items = (int)O.items;
+    if (o == 0) {
+        d_pixels = (const uint8_t*)d_pixels + (size_t)first * s->W * s->H * s->C;
+        if (s->up) {
+            // source size as the reference derives it (sift.cpp:1144-1145)
+            const int ws = (int)((float)O.w / kResampleRatio), hs = (int)((float)O.h / kResampleRatio);
+            const dim3 g((O.w + 255) / 256, O.h, nf);
+            if (s->C == 3)
+                hipLaunchKernelGGL(k_base_upscaled<3>, g, dim3(256), 0, run, (const uint8_t*)d_pixels, O.base, O.w,
+                                   O.h, ws, hs, kResampleRatio);
+            else
+                hipLaunchKernelGGL(k_base_upscaled<1>, g, dim3(256), 0, run, (const uint8_t*)d_pixels, O.base, O.w,
+                                   O.h, ws, hs, kResampleRatio);
+        } else if (s->C == 3 && items % 4 == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 3u) == 0)
+            hipLaunchKernelGGL(k_gray_bgr_x4, dim3((items / 4 + 255) / 256, 1, nf), dim3(256), 0, run,
+                               (const uint8_t*)d_pixels, O.base, items);
+        else if (s->C == 3)
+            hipLaunchKernelGGL(k_gray_bgr, dim3((items + 255) / 256, 1, nf), dim3(256), 0, run,
+                               (const uint8_t*)d_pixels, O.base, items);
+        else if (items % 4 == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 3u) == 0)
+            hipLaunchKernelGGL(k_gray_u8_x4, dim3((items / 4 + 255) / 256, 1, nf), dim3(256), 0, run,
+                               (const uint8_t*)d_pixels, O.base, items);
+        else
+            hipLaunchKernelGGL(k_gray_u8, dim3((items + 255) / 256, 1, nf), dim3(256), 0, run,
+                               (const uint8_t*)d_pixels, O.base, items);
+    } else {
+        const size_t prev_stride = s->oct[o - 1].items * kLevels;
+        hipLaunchKernelGGL(k_decimate, dim3((O.w + 255) / 256, O.h, nf), dim3(256), 0, run,
+                           (const float*)s->oct[o - 1].pyr + (size_t)first * prev_stride, prev_stride, O.base, O.w, O.h);
+    }
 }
 
 // Phase 1 of a batch: base images and scale spaces (+ DoG) of all octaves. Only bandwidth
@@ -1342,42 +1433,31 @@ int enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes, bool split =
         if (split && o > 0 && last_l3 >= 0) MIF_HIP(hipStreamWaitEvent(run, s->ev_l3[last_l3], 0));
         const size_t pyr_stride = O.items * kLevels;
         if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][0], st));
-        if (o == 0) {
-            if (s->up) {
-                // source size as the reference derives it (sift.cpp:1144-1145)
-                const int ws = (int)((float)O.w / kResampleRatio), hs = (int)((float)O.h / kResampleRatio);
-                const dim3 g((O.w + 255) / 256, O.h, nf);
-                if (s->C == 3)
-                    hipLaunchKernelGGL(k_base_upscaled<3>, g, dim3(256), 0, run, (const uint8_t*)d_pixels, O.base, O.w,
-                                       O.h, ws, hs, kResampleRatio);
-                else
-                    hipLaunchKernelGGL(k_base_upscaled<1>, g, dim3(256), 0, run, (const uint8_t*)d_pixels, O.base, O.w,
-                                       O.h, ws, hs, kResampleRatio);
-            } else if (s->C == 3 && items % 4 == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 3u) == 0)
-                hipLaunchKernelGGL(k_gray_bgr_x4, dim3((items / 4 + 255) / 256, 1, nf), dim3(256), 0, run,
-                                   (const uint8_t*)d_pixels, O.base, items);
-            else if (s->C == 3)
-                hipLaunchKernelGGL(k_gray_bgr, dim3((items + 255) / 256, 1, nf), dim3(256), 0, run,
-                                   (const uint8_t*)d_pixels, O.base, items);
-            else if (items % 4 == 0 && (reinterpret_cast<uintptr_t>(d_pixels) & 3u) == 0)
-                hipLaunchKernelGGL(k_gray_u8_x4, dim3((items / 4 + 255) / 256, 1, nf), dim3(256), 0, run,
-                                   (const uint8_t*)d_pixels, O.base, items);
-            else
-                hipLaunchKernelGGL(k_gray_u8, dim3((items + 255) / 256, 1, nf), dim3(256), 0, run,
-                                   (const uint8_t*)d_pixels, O.base, items);
-        } else {
-            hipLaunchKernelGGL(k_decimate, dim3((O.w + 255) / 256, O.h, nf), dim3(256), 0, run,
-                               (const float*)s->oct[o - 1].pyr, s->oct[o - 1].items * kLevels, O.base, O.w, O.h);
-        }
+        // The level-0 launch forms the base image itself while it stages its window (see k_blur_level);
+        // only the resampled first octave of up_scale is written out by a kernel of its own.
+        const bool fused_base = s->fused_base && !(o == 0 && s->up);
+        if (!fused_base) write_base(s, o, d_pixels, 0, nf, run);
         if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][1], st));
         // level 0 blurs the base image with sigma 1.6; level l >= 1 blurs level l-1
         // (sift.cpp:1196-1218); DoG[l-1] = level l - level l-1 (sift.cpp:256-260) is formed by its readers
         for (int l = 0; l < kLevels; l++) {
-            const float* src = (l == 0) ? O.base : O.pyr + (size_t)(l - 1) * items;
-            const size_t src_stride = (l == 0) ? O.items : pyr_stride;
+            const void* src = (l == 0) ? O.base : O.pyr + (size_t)(l - 1) * items;
+            size_t src_stride = (l == 0) ? O.items : pyr_stride;
+            int kind = kSrcFloat;
+            if (l == 0 && fused_base) {
+                if (o == 0) {
+                    src = d_pixels;
+                    src_stride = O.items * (size_t)s->C;
+                    kind = s->C == 3 ? kSrcBgrU8 : kSrcGrayU8;
+                } else {
+                    src = s->oct[o - 1].pyr;
+                    src_stride = s->oct[o - 1].items * kLevels;
+                    kind = kSrcDecimated;
+                }
+            }
             float* dst = O.pyr + (size_t)l * items;
             const int rc = launch_blur(s->fr[l], src, src_stride, dst, pyr_stride, O.w, O.h, nf, s->ktaps[l],
-                                       s->zero_row, run);
+                                       s->zero_row, run, kind);
             if (rc != MIF_OK) return rc;
             if (split && l == kIntervals) {             // level 3 feeds the next octave
                 MIF_HIP(hipEventRecord(s->ev_l3[o], run));
@@ -1389,6 +1469,7 @@ int enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes, bool split =
     MIF_HIP(hipGetLastError());
     s->pyramid_frames = nf;
     s->pyramid_split = split;
+    s->last_pixels = d_pixels;
     return MIF_OK;
 }
 
@@ -1553,7 +1634,6 @@ int create_impl(mif_sift* s)
         O.rows = kIntervals * O.h;
         s->cap += O.maxf;
         if (O.items == 0) continue;
-        MIF_HIP(hipMalloc(&O.base, B * O.items * sizeof(float)));
         MIF_HIP(hipMalloc(&O.pyr, B * O.items * kLevels * sizeof(float)));
         MIF_HIP(hipMalloc(&O.grad, B * O.items * kIntervals * sizeof(float2)));
         MIF_HIP(hipMalloc(&O.mask, B * O.rows * O.words * sizeof(unsigned long long)));
@@ -1574,6 +1654,15 @@ int create_impl(mif_sift* s)
     MIF_HIP(hipHostMalloc(&s->h_counts, B * CNT_WORDS * sizeof(int)));
     build_taps(s->taps, s->fr);
     build_ori_bins(&s->ori_bins);
+    // a BGR pixel is fetched as a 32-bit word, which needs rows of at least four bytes
+    s->fused_base = s->fr[0] == kBaseRadius && s->oct[kOctaves - 1].w >= 2 && getenv("MIF_NO_FUSED_BASE") == nullptr;
+    for (int o = 0; o < kOctaves; o++) {
+        OctaveBuf& O = s->oct[o];
+        if (O.items == 0) continue;
+        // stored for the whole batch only where a kernel of its own writes it; one frame for the probe otherwise
+        const bool stored = !s->fused_base || (s->up && o == 0);
+        MIF_HIP(hipMalloc(&O.base, (stored ? B : 1) * O.items * sizeof(float)));
+    }
     for (int l = 0; l < kLevels; l++) {
         memset(&s->ktaps[l], 0, sizeof(Taps));
         if ((int)s->taps[l].size() > kMaxTaps) {
@@ -1874,8 +1963,21 @@ int mif_sift_copy_base(mif_sift* s, int frame, int octave, float* out)
     mif::DeviceGuard guard(s->device);
     const OctaveBuf& O = s->oct[octave];
     MIF_HIP(hipStreamSynchronize(s->stream));
-    if (O.items)
-        MIF_HIP(hipMemcpy(out, O.base + (size_t)frame * O.items, O.items * sizeof(float), hipMemcpyDeviceToHost));
+    if (!O.items) return MIF_OK;
+    const bool stored = !s->fused_base || (octave == 0 && s->up);
+    if (!stored) {
+        // not kept by the extraction: formed now from the pixels of the last call (octave 0) or from the
+        // previous octave's scale space
+        if (octave == 0 && !s->last_pixels) {
+            mif::set_error("mif_sift_copy_base: no frame has been processed yet");
+            return MIF_ERR_INVALID_ARGUMENT;
+        }
+        write_base(s, octave, s->last_pixels, frame, 1, s->stream);
+        MIF_HIP(hipGetLastError());
+        MIF_HIP(hipStreamSynchronize(s->stream));
+    }
+    MIF_HIP(hipMemcpy(out, O.base + (stored ? (size_t)frame * O.items : 0), O.items * sizeof(float),
+                      hipMemcpyDeviceToHost));
     return MIF_OK;
 }
 
