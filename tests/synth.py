@@ -2,9 +2,11 @@
 import numpy as np
 
 
-def blob_image(width, height, seed, n_blobs=None, channels=1, shift=(0, 0)):
+def blob_image(width, height, seed, n_blobs=None, channels=1, shift=(0, 0), wrap=False):
     """Gaussian blobs over a smooth gradient plus noise, clipped to uint8. `shift`
-    translates the blob field so consecutive frames of a sequence can be matched."""
+    translates the blob field so consecutive frames of a sequence can be matched; with
+    `wrap` blobs that leave on one side come back on the other, so every frame of a long
+    sequence holds the same number of blobs."""
     rng = np.random.RandomState(seed)
     if n_blobs is None:
         n_blobs = max(8, width * height // 300)
@@ -12,6 +14,8 @@ def blob_image(width, height, seed, n_blobs=None, channels=1, shift=(0, 0)):
     img = 60.0 + 40.0 * (xx / max(width - 1, 1)) + 30.0 * (yy / max(height - 1, 1))
     cx = rng.uniform(0, width, n_blobs) + shift[0]
     cy = rng.uniform(0, height, n_blobs) + shift[1]
+    if wrap:
+        cx, cy = cx % width, cy % height
     sg = rng.uniform(1.5, 9.0, n_blobs)
     am = rng.uniform(40.0, 200.0, n_blobs) * rng.choice([-1.0, 1.0], n_blobs)
     for i in range(n_blobs):
