@@ -557,6 +557,11 @@ __device__ bool refine_pixel(const float* __restrict__ pyr, size_t items, int w,
 // with an integer atomic (order independent). The refinement, which needs many
 // more registers than this loop, is a kernel of its own (k_refine).
 constexpr int kDetCols = 62;        // output columns per wave
+// (double)|v| > 0.0108333 (sift.cpp:288, the literal is a double) holds for a float v exactly when
+// |v| exceeds the largest float that is not above the literal, so the test needs no conversion.
+constexpr float kContrPre = ((double)(float)K_CONTR_THR_1 <= K_CONTR_THR_1)
+                                ? (float)K_CONTR_THR_1
+                                : __builtin_nextafterf((float)K_CONTR_THR_1, 0.0f);
 constexpr int kDetRows = 32;        // rows per block
 constexpr int kDetGroup = 3;        // rows loaded ahead
 
@@ -579,14 +584,17 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ pyr, s
     pyr += (size_t)f * pyr_stride;
     cmask += (size_t)f * kIntervals * h * words;
     if (GRAD) grad += (size_t)f * grad_stride;
-    const bool xin = x >= 0 && x < w;
     const bool xgrad = lane >= 1 && lane <= kDetCols && x >= 1 && x <= w - 2;
     const bool xtest = lane >= 1 && lane <= kDetCols && x > kBorder && x < w - kBorder;
     // one row of the six pyramid levels; the five DoG values are formed when the row enters the window
+    // Positions outside the image are read from the nearest pixel inside instead: such values only
+    // reach pixels closer than kBorder to the edge (extremum test) or on the edge itself (gradients),
+    // which are never tested resp. written, so the loads need neither a branch nor a select.
+    const int xc = min(max(x, 0), w - 1);
     auto load_row = [&](int y, float v[kLevels]) {
-        const bool ok = xin && y >= 0 && y < h;
+        const float* p = pyr + (size_t)min(max(y, 0), h - 1) * w + xc;
 #pragma unroll
-        for (int l = 0; l < kLevels; l++) v[l] = ok ? pyr[l * items + (size_t)y * w + x] : 0.0f;
+        for (int l = 0; l < kLevels; l++) v[l] = p[l * items];
     };
     // nb[l][r][c]: rows r = 0..2 <-> y-1, y, y+1; columns c = 0..2 <-> x-1, x, x+1
     float nb[kLevels - 1][3][3];
@@ -689,7 +697,7 @@ __global__ __launch_bounds__(256) void k_detect(const float* __restrict__ pyr, s
 #pragma unroll
             for (int s = 1; s <= kIntervals; s++) {
                 const float cur = cen[s - 1];
-                const bool cand = inside && (double)mif_fabsf(cur) > K_CONTR_THR_1 &&
+                const bool cand = inside && mif_fabsf(cur) > kContrPre &&
                                   ((cur > maxP[s - 1] && cur > maxC[s - 1] && cur > max9[s - 1]) ||
                                    (cur < minP[s - 1] && cur < minC[s - 1] && cur < min9[s - 1]));
                 if (cand)                                               // about one lane in a hundred
