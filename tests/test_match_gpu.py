@@ -123,13 +123,10 @@ def test_sharded_database_merge_equals_single_search():
     assert np.array_equal(i1, ref_idx) and np.array_equal(d1.view(np.uint32), ref_d.view(np.uint32))
 
 
-def test_many_pairs_with_device_counts_and_uneven_sizes():
-    """40 pairs in one call (more than one launch's pair table) with row counts in device memory,
-    including empty and single-row sides; every pair equals the checker."""
+def _many_pairs(P, cap, seed, m=None):
     import torch
     dev = torch.device("cuda:0")
-    rng = np.random.RandomState(11)
-    P, cap = 40, 700
+    rng = np.random.RandomState(seed)
     nq = [int(v) for v in rng.randint(0, cap, P)]
     nd = [int(v) for v in rng.randint(0, cap, P)]
     nq[0], nd[1], nd[2], nq[3] = 0, 0, 1, 1
@@ -137,8 +134,8 @@ def test_many_pairs_with_device_counts_and_uneven_sizes():
     D = torch.zeros((P, cap, 128), dtype=torch.float32, device=dev)
     host = []
     for p in range(P):
-        q = sift_like_descriptors(max(nq[p], 1), seed=100 + p)[:nq[p]]
-        d = sift_like_descriptors(max(nd[p], 1), seed=500 + p)[:nd[p]]
+        q = sift_like_descriptors(max(nq[p], 1), seed=seed * 1000 + p)[:nq[p]]
+        d = sift_like_descriptors(max(nd[p], 1), seed=seed * 1000 + 500 + p)[:nd[p]]
         if nq[p] and nd[p] > 3:
             d[nd[p] // 2] = q[0]                     # an exact hit
         host.append((q, d))
@@ -148,7 +145,7 @@ def test_many_pairs_with_device_counts_and_uneven_sizes():
     cd = torch.tensor(nd, dtype=torch.int32, device=dev)
     idx = torch.full((P, cap, 2), -9, dtype=torch.int32, device=dev)
     dist = torch.zeros((P, cap, 2), dtype=torch.float32, device=dev)
-    m = oda.Matcher(cap, cap, max_pairs=P)
+    m = m or oda.Matcher(cap, cap, max_pairs=P)
     pairs = [dict(q=Q[p].data_ptr(), db=D[p].data_ptr(), nq=cq[p:].data_ptr(), nd=cd[p:].data_ptr(),
                   idx2=idx[p].data_ptr(), dist2=dist[p].data_ptr()) for p in range(P)]
     m.top2_batch_device(pairs, cap, cap, 128, 128, 0)
@@ -160,3 +157,18 @@ def test_many_pairs_with_device_counts_and_uneven_sizes():
         i_o, d_o = orc.match_top2(q, d)
         assert np.array_equal(idx[p, :nq[p]], i_o), p
         assert np.array_equal(dist[p, :nq[p]].view(np.uint32), d_o.view(np.uint32)), p
+    return m
+
+
+def test_many_pairs_with_device_counts_and_uneven_sizes():
+    """40 pairs in one call with row counts in device memory, including empty and single-row
+    sides; every pair equals the checker."""
+    _many_pairs(40, 700, seed=11)
+
+
+def test_more_pairs_than_one_launch_and_table_reuse():
+    """300 pairs in one call (the pair table of a launch holds 256, so two launches) and six calls on
+    one matcher with different tables (the device-side tables are used in rotation)."""
+    m = _many_pairs(300, 96, seed=12)
+    for call in range(5):
+        _many_pairs(7 + 50 * call, 96, seed=20 + call, m=m)
