@@ -21,6 +21,8 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kQT = 32;      // query rows per wave (one 32x32 MFMA tile)
 constexpr int kWaves = 4;    // waves per block, each with its own query tile
@@ -28,6 +30,14 @@ constexpr int kDC = 64;      // database rows per staged chunk (two MFMA tiles)
 constexpr float kInf = __builtin_inff();
 constexpr int kMaxPairs = 256;  // pairs per launch (their item ranges are cached in LDS)
 constexpr int kTableSlots = 4;  // pair tables in flight per matcher
+constexpr int kCandCap = 32;    // candidates kept per query by the screening passes
+// Screening (see k_match_screen): a bf16 score differs from the fp32 ranking score by at most
+// kScreenRel * |q| * |d| + kScreenAbs * (|q|^2 + |d|^2): two operands rounded to 8 significant bits
+// (2^-9 each), products exact, 128 accumulations in the matrix unit (allowed 2^-22 each), the fp32
+// chain's own 128 roundings, all times the factor 2 of the score and |sum q d| <= |q| |d|:
+// 2 * (2 * 2^-9 + 2^-18 + 128 * 2^-22 + 128 * 2^-24) = 0.0079, rounded up; the absolute term covers
+// the roundings of |q|^2 + |d|^2 and of the final fused multiply-add.
+constexpr float kScreenRel = 0.0085f, kScreenAbs = 1e-6f;
 
 // The pair table of a call lives in device memory (copied there on the call's stream), so that
 // one launch can serve a whole batch of frame pairs: few launches mean few tails.
@@ -55,7 +65,7 @@ __device__ __forceinline__ void load_span(const float* __restrict__ r, int n, fl
 // are all in flight before the (strictly sequential) fmaf chain consumes them.
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_row_norms(PairTable tbl, int which, int n_cap, int dim, int ld,
-                                                   float* __restrict__ out)
+                                                   float* __restrict__ out, unsigned int* __restrict__ nmax)
 {
     const mif_match_pair& pr = tbl[blockIdx.y];
     const float* __restrict__ m = which ? pr.d_db : pr.d_q;
@@ -77,6 +87,8 @@ __global__ __launch_bounds__(256) void k_row_norms(PairTable tbl, int which, int
             if (k < span) acc = __builtin_fmaf(v[k], v[k], acc);
     }
     out[i] = acc;
+    // largest squared norm of the pair's rows (non-negative floats order like their bit patterns)
+    if (nmax) atomicMax(&nmax[blockIdx.y], __builtin_bit_cast(unsigned int, acc));
 }
 
 struct Top2 {
@@ -390,6 +402,303 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int npairs
   }
 }
 
+// ---------------------------------------------------------------- screening
+//
+// The exact search above spends its time in fp32 matrix instructions. For batches of small problems
+// (frame against frame) the same answer comes much cheaper: bf16 matrix instructions run 16 times
+// as fast, and a bf16 score s~ differs from the fp32 ranking score s by at most a margin m that
+// follows from the norms (kScreenRel, kScreenAbs). If t is the second smallest s~ of a query, every
+// row among the query's true two nearest has s~ <= t + 2 m: the two rows with the smallest s~ have
+// s <= t + m, so the second smallest s is <= t + m, and a row with s <= t + m has s~ <= t + 2 m.
+//   pass 0: t per query (branch-free running two smallest), threshold = t + 2 m
+//   pass 1: the rows with s~ <= threshold are appended to the query's candidate list
+//   k_match_rank: fp32 ranking scores of the candidates, computed exactly as the exact search does
+//     (fmaf chain in ascending k, fmaf(-2, dot, |q|^2 + |d|^2)), two smallest (score, index); a
+//     query whose list overflowed (or holds fewer rows than it must) is ranked against all rows.
+// The result is therefore the exact search's, bit for bit; the bf16 values only decide which rows
+// are looked at. Same block structure as k_match_partial: 4 waves x 32 queries, database chunks of
+// 64 rows staged in LDS (as bf16, converted while staging), persistent blocks drawing
+// (pair, 128-query tile) items; one item walks all rows of its pair.
+template <int K, bool VEC, int PASS>
+__global__ __launch_bounds__(256) void k_match_screen(PairTable tbl, int npairs, int nq_cap, int nd_cap, int dim,
+                                                      int ld, const float* __restrict__ qn_all,
+                                                      const float* __restrict__ dn_all,
+                                                      const unsigned int* __restrict__ dnmax_all,
+                                                      float* __restrict__ thr_all, int* __restrict__ cnt_all,
+                                                      int* __restrict__ cand_all,
+                                                      unsigned int* __restrict__ work_counter)
+{
+    constexpr int KS = K / 16;                 // matrix instructions per tile
+    constexpr int KPB = K + 8;                 // row pitch in bf16 elements (16 bytes of padding)
+    constexpr int K4 = K / 4;                  // float4 per staged row
+    constexpr int NV = kDC * K4 / 256;         // float4 staged per thread and chunk
+    constexpr int RSTEP = 256 / K4;            // rows between a thread's consecutive float4
+    __shared__ __attribute__((aligned(16))) __bf16 s_b[2][kDC * KPB];
+    __shared__ __attribute__((aligned(16))) float s_dn[2][kDC];
+    __shared__ int s_first[kMaxPairs + 1];
+    __shared__ int s_rows[kMaxPairs][2];
+    __shared__ int s_item;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+
+    for (int z = tid; z < kMaxPairs; z += 256) {
+        int cnt = 0;
+        if (z < npairs) {
+            const mif_match_pair& pz = tbl[z];
+            const int nqz = pz.d_nq ? min(*pz.d_nq, nq_cap) : nq_cap;
+            const int ndz = pz.d_nd ? min(*pz.d_nd, nd_cap) : nd_cap;
+            s_rows[z][0] = nqz;
+            s_rows[z][1] = ndz;
+            cnt = ndz > 0 ? (nqz + kQT * kWaves - 1) / (kQT * kWaves) : 0;
+        }
+        s_first[z + 1] = cnt;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        constexpr int PER = kMaxPairs / 64;
+        int c[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { c[j] = s_first[tid * PER + j + 1]; sum += c[j]; }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (tid >= d) incl += o;
+        }
+        int run = incl - sum;
+        if (tid == 0) s_first[0] = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { run += c[j]; s_first[tid * PER + j + 1] = run; }
+        if (tid == 0) s_item = (int)atomicAdd(work_counter, 1u);
+    }
+
+    const int k4 = tid % K4;
+    const int r0 = tid / K4;
+    const bool m0 = 4 * k4 + 0 < dim, m1 = 4 * k4 + 1 < dim, m2 = 4 * k4 + 2 < dim, m3 = 4 * k4 + 3 < dim;
+    const int kc0 = min(4 * k4 + 0, dim - 1), kc1 = min(4 * k4 + 1, dim - 1);
+    const int kc2 = min(4 * k4 + 2, dim - 1), kc3 = min(4 * k4 + 3, dim - 1);
+    const int k4c = m0 ? 4 * k4 : 0;
+
+  for (;;) {
+    __syncthreads();
+    const int item = __builtin_amdgcn_readfirstlane(s_item);
+    __syncthreads();
+    if (item >= s_first[kMaxPairs]) break;     // uniform over the block
+    int next_item = 0;
+    if (tid == 0) next_item = (int)atomicAdd(work_counter, 1u);
+    int z = 0;
+    {
+        int hi = npairs - 1;
+        while (z < hi) {
+            const int mid = (z + hi + 1) >> 1;
+            if (s_first[mid] <= item) z = mid; else hi = mid - 1;
+        }
+    }
+    z = __builtin_amdgcn_readfirstlane(z);
+    const mif_match_pair& pr = tbl[z];
+    const float* __restrict__ Q = pr.d_q;
+    const float* __restrict__ D = pr.d_db;
+    const float* __restrict__ qn = qn_all + (size_t)z * nq_cap;
+    const float* __restrict__ dn = dn_all + (size_t)z * nd_cap;
+    float* __restrict__ thr = thr_all + (size_t)z * nq_cap;
+    int* __restrict__ cnt = cnt_all + (size_t)z * nq_cap;
+    int* __restrict__ cand = cand_all + (size_t)z * nq_cap * kCandCap;
+    const int nq = __builtin_amdgcn_readfirstlane(s_rows[z][0]);
+    const int nd = __builtin_amdgcn_readfirstlane(s_rows[z][1]);
+    const int qbase = (item - s_first[z]) * (kQT * kWaves) + wave * kQT;
+    const int qi = qbase + col;
+    const int chunks = (nd + kDC - 1) / kDC;
+
+    float4 stage[NV];
+    float stage_dn = 0.0f;
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int it = 0; it < NV; it++) {
+            const int j = min(c * kDC + r0 + RSTEP * it, nd - 1);
+            const float* src = D + (size_t)j * ld;
+            if (VEC) stage[it] = *reinterpret_cast<const float4*>(src + k4c);
+            else stage[it] = make_float4(src[kc0], src[kc1], src[kc2], src[kc3]);
+        }
+        stage_dn = dn[min(c * kDC + (tid & (kDC - 1)), nd - 1)];
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < NV; it++) {
+            const int r = r0 + RSTEP * it;
+            const float4 v = stage[it];
+            bf16x4 b;
+            b[0] = (__bf16)(m0 ? v.x : 0.0f); b[1] = (__bf16)(m1 ? v.y : 0.0f);
+            b[2] = (__bf16)(m2 ? v.z : 0.0f); b[3] = (__bf16)(m3 ? v.w : 0.0f);
+            *reinterpret_cast<bf16x4*>(&s_b[buf][r * KPB + 4 * k4]) = b;
+        }
+        if (tid < kDC) s_dn[buf][tid] = stage_dn;
+    };
+    load_chunk(0);
+
+    // queries (B operand): lane holds q[qbase + col][16 j + 8 half .. + 7] for every instruction j
+    bf16x8 qf[KS];
+    {
+        const float* qr = Q + (size_t)min(qi, nq - 1) * ld;
+        const bool row_ok = qi < nq;
+#pragma unroll
+        for (int j = 0; j < KS; j++) {
+            const int k0 = 16 * j + 8 * half;
+            float e[8];
+            if (VEC) {
+                const float4 u = *reinterpret_cast<const float4*>(qr + min(k0, (dim - 1) & ~3));
+                const float4 w = *reinterpret_cast<const float4*>(qr + min(k0 + 4, (dim - 1) & ~3));
+                e[0] = u.x; e[1] = u.y; e[2] = u.z; e[3] = u.w; e[4] = w.x; e[5] = w.y; e[6] = w.z; e[7] = w.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) e[i] = qr[min(k0 + i, dim - 1)];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) qf[j][i] = (__bf16)((row_ok && k0 + i < dim) ? e[i] : 0.0f);
+        }
+    }
+    const float qnv = (qi < nq) ? qn[qi] : 0.0f;
+    float t1 = kInf, t2 = kInf;                 // pass 0: the two smallest scores seen
+    const float limit = (PASS == 1 && qi < nq) ? thr[qi] : -kInf;
+    int filled = 0;                             // pass 1: rows appended to the query's list so far
+
+    auto consider = [&](const f32x16& acc, int jbase, const float* dnp, bool full) {
+        float sc[16];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 dn4 = *reinterpret_cast<const float4*>(&dnp[8 * g + 4 * half]);
+            sc[4 * g + 0] = __builtin_fmaf(-2.0f, acc[4 * g + 0], qnv + dn4.x);
+            sc[4 * g + 1] = __builtin_fmaf(-2.0f, acc[4 * g + 1], qnv + dn4.y);
+            sc[4 * g + 2] = __builtin_fmaf(-2.0f, acc[4 * g + 2], qnv + dn4.z);
+            sc[4 * g + 3] = __builtin_fmaf(-2.0f, acc[4 * g + 3], qnv + dn4.w);
+        }
+        if (!full) {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (jbase + (r & 3) + 8 * (r >> 2) + 4 * half >= nd) sc[r] = kInf;
+        }
+        if (PASS == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                t2 = __builtin_amdgcn_fmed3f(t1, t2, sc[r]);     // t1 <= t2: the middle one is the new second
+                t1 = fminf(t1, sc[r]);
+            }
+        } else {
+            float mn = sc[0];
+#pragma unroll
+            for (int r = 1; r < 16; r++) mn = fminf(mn, sc[r]);
+            // A query's rows are seen by the two lanes l, l + 32 of this wave only, so its list is
+            // filled without atomics: the branch is uniform over the wave, the lower lane's rows of
+            // a tile go first, and both lanes keep the same running count.
+            if (__builtin_amdgcn_ballot_w64(mn <= limit) != 0ull) {
+                unsigned int hits = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; r++) hits |= (sc[r] <= limit ? 1u : 0u) << r;
+                const int mine = __popc(hits);
+                const int other = __shfl_xor(mine, 32);
+                int at = filled + (half ? other : 0);
+                filled += mine + other;
+                while (hits != 0u) {
+                    const int r = __ffs((int)hits) - 1;
+                    hits &= hits - 1u;
+                    if (at < kCandCap) cand[(size_t)qi * kCandCap + at] = jbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    at++;
+                }
+            }
+        }
+    };
+    auto chunk_step = [&](int c, int buf) {
+        store_chunk(buf);
+        __syncthreads();
+        load_chunk(min(c + 1, chunks - 1));
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+        const __bf16* ap0 = &s_b[buf][col * KPB + 8 * half];
+        const __bf16* ap1 = &s_b[buf][(32 + col) * KPB + 8 * half];
+#pragma unroll
+        for (int j = 0; j < KS; j++) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap0 + 16 * j);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(ap1 + 16 * j);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, qf[j], acc1, 0, 0, 0);
+        }
+        const bool full = (c + 1) * kDC <= nd;
+        consider(acc0, c * kDC, &s_dn[buf][0], full);
+        consider(acc1, c * kDC + 32, &s_dn[buf][32], full);
+    };
+    for (int c = 0; c < chunks; c += 2) {
+        chunk_step(c, 0);
+        if (c + 1 < chunks) chunk_step(c + 1, 1);
+    }
+    if (PASS == 0) {
+        // lanes l and l + 32 hold the same query (interleaved database rows)
+        const float o1 = __shfl_xor(t1, 32), o2 = __shfl_xor(t2, 32);
+        t2 = __builtin_amdgcn_fmed3f(t1, t2, o1); t1 = fminf(t1, o1);
+        t2 = __builtin_amdgcn_fmed3f(t1, t2, o2); t1 = fminf(t1, o2);
+        if (half == 0 && qi < nq) {
+            const float dmax = __builtin_bit_cast(float, dnmax_all[z]);
+            const float m = kScreenRel * __builtin_sqrtf(qnv * dmax) + kScreenAbs * (qnv + dmax);
+            thr[qi] = t2 + 2.0f * m;            // +inf while fewer than two rows exist: every row is kept
+        }
+    } else if (half == 0 && qi < nq) {
+        cnt[qi] = filled;
+    }
+    if (tid == 0) s_item = next_item;
+  }
+}
+
+// Ranks the candidates of the screening passes with the exact search's arithmetic and writes the
+// two winners where k_match_partial would have written them (split 0), for k_match_finalize.
+// grid (ceil(nq_cap/128), npairs), one thread per query.
+template <bool VEC>
+__global__ __launch_bounds__(128) void k_match_rank(PairTable tbl, int nq_cap, int nd_cap, int dim, int ld,
+                                                    const float* __restrict__ qn_all, const float* __restrict__ dn_all,
+                                                    const int* __restrict__ cnt_all, const int* __restrict__ cand_all,
+                                                    float* __restrict__ part_s_all, int* __restrict__ part_i_all,
+                                                    int part_stride)
+{
+    const mif_match_pair& pr = tbl[blockIdx.y];
+    const int nq = pr.d_nq ? min(*pr.d_nq, nq_cap) : nq_cap;
+    const int nd = pr.d_nd ? min(*pr.d_nd, nd_cap) : nd_cap;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const float* __restrict__ Q = pr.d_q;
+    const float* __restrict__ D = pr.d_db;
+    const float qnv = qn_all[(size_t)blockIdx.y * nq_cap + i];
+    const float* __restrict__ dn = dn_all + (size_t)blockIdx.y * nd_cap;
+    const int* __restrict__ cand = cand_all + ((size_t)blockIdx.y * nq_cap + i) * kCandCap;
+    int n = nd > 0 ? cnt_all[(size_t)blockIdx.y * nq_cap + i] : 0;
+    // a list that overflowed, or that holds fewer rows than the answer has, is not trusted
+    const bool all_rows = n > kCandCap || n < min(2, nd);
+    if (all_rows) n = nd;
+    Top2 t;
+    t.s1 = t.s2 = kInf;
+    t.i1 = t.i2 = 0x7fffffff;
+    const float* q = Q + (size_t)i * ld;
+    for (int c = 0; c < n; c++) {
+        const int j = all_rows ? c : cand[c];
+        const float* r = D + (size_t)j * ld;
+        float acc = 0.0f;
+        for (int k0 = 0; k0 < dim; k0 += 32) {
+            const int span = min(32, dim - k0);
+            const int avail = min(32, ld - k0);
+            float vq[32], vd[32];
+            load_span<VEC>(q + k0, avail, vq);
+            load_span<VEC>(r + k0, avail, vd);
+#pragma unroll
+            for (int k = 0; k < 32; k++)
+                if (k < span) acc = __builtin_fmaf(vd[k], vq[k], acc);
+        }
+        top2_insert(t, __builtin_fmaf(-2.0f, acc, qnv + dn[j]), j);
+    }
+    const size_t o = (size_t)blockIdx.y * part_stride + (size_t)i * 2;
+    part_s_all[o] = t.s1; part_s_all[o + 1] = t.s2;
+    part_i_all[o] = t.i1; part_i_all[o + 1] = t.i2;
+}
+
 // grid (ceil(nq_cap/128), npairs). A thread owns a query: it merges the splits'
 // candidates, then evaluates the exact distances of both winners together, one
 // span of 32 elements at a time (all loads of a span in flight, then the two
@@ -532,7 +841,12 @@ struct mif_matcher {
     int* d_idx = nullptr;
     float* d_dist = nullptr;
     float* d_score = nullptr;
-    unsigned int* work = nullptr;   // work-item counter of k_match_partial
+    unsigned int* work = nullptr;   // work-item counters: [0] exact search, [1], [2] screening passes
+    // screening: largest database norm per pair, threshold / count / candidates per query
+    unsigned int* dnmax = nullptr;  // [pairs]
+    float* thr = nullptr;           // [pairs][max_q]
+    int* cand_cnt = nullptr;        // [pairs][max_q]
+    int* cand = nullptr;            // [pairs][max_q][kCandCap]
     // pair tables: pinned host copies and their device twins, used in rotation; a slot is reused
     // once the call that read it last has finished on the GPU (slot_ev)
     mif_match_pair* h_tbl[kTableSlots] = {};
@@ -546,12 +860,17 @@ struct mif_matcher {
 namespace {
 
 constexpr int kMaxSplit = 64;
+// Batches of at least this many pairs whose database needs no split (enough work items without
+// one) go through the bf16 screening passes; single pairs and large databases keep the plain
+// exact search, whose cost does not depend on how many near-ties the data hold.
+constexpr int kScreenMinPairs = 8;
 
 void free_matcher(mif_matcher* m)
 {
     (void)hipFree(m->qn); (void)hipFree(m->dn); (void)hipFree(m->part_s); (void)hipFree(m->part_i);
     (void)hipFree(m->d_q); (void)hipFree(m->d_db); (void)hipFree(m->d_idx); (void)hipFree(m->d_dist);
     (void)hipFree(m->d_score); (void)hipFree(m->work);
+    (void)hipFree(m->dnmax); (void)hipFree(m->thr); (void)hipFree(m->cand_cnt); (void)hipFree(m->cand);
     for (int i = 0; i < kTableSlots; i++) {
         if (m->h_tbl[i]) (void)hipHostFree(m->h_tbl[i]);
         (void)hipFree(m->d_tbl[i]);
@@ -628,23 +947,53 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
             vec_db = vec_db && ((reinterpret_cast<uintptr_t>(hp[i].d_db) & 15u) == 0);
             vec_q = vec_q && ((reinterpret_cast<uintptr_t>(hp[i].d_q) & 15u) == 0);
         }
+        static const bool no_screen = getenv("MIF_MATCH_NO_SCREEN") != nullptr;      // A/B switch
+        const bool screen = !no_screen && m->cand && np >= kScreenMinPairs && nsplit == 1 && nd >= 2 * kDC;
         if (nd > 0) {
+            unsigned int* nmax = screen ? m->dnmax + base : nullptr;
+            if (screen) MIF_HIP(hipMemsetAsync(nmax, 0, (size_t)np * sizeof(unsigned int), st));
             if (vec_db)
-                hipLaunchKernelGGL(k_row_norms<true>, dim3((nd + 255) / 256, np), dim3(256), 0, st, tbl, 1, nd, dim, ld, dn);
+                hipLaunchKernelGGL(k_row_norms<true>, dim3((nd + 255) / 256, np), dim3(256), 0, st, tbl, 1, nd, dim, ld, dn, nmax);
             else
-                hipLaunchKernelGGL(k_row_norms<false>, dim3((nd + 255) / 256, np), dim3(256), 0, st, tbl, 1, nd, dim, ld, dn);
+                hipLaunchKernelGGL(k_row_norms<false>, dim3((nd + 255) / 256, np), dim3(256), 0, st, tbl, 1, nd, dim, ld, dn, nmax);
             if (vec_q)
-                hipLaunchKernelGGL(k_row_norms<true>, dim3((nq + 255) / 256, np), dim3(256), 0, st, tbl, 0, nq, dim, ld, qn);
+                hipLaunchKernelGGL(k_row_norms<true>, dim3((nq + 255) / 256, np), dim3(256), 0, st, tbl, 0, nq, dim, ld, qn, (unsigned int*)nullptr);
             else
-                hipLaunchKernelGGL(k_row_norms<false>, dim3((nq + 255) / 256, np), dim3(256), 0, st, tbl, 0, nq, dim, ld, qn);
-            MIF_HIP(hipMemsetAsync(m->work, 0, sizeof(unsigned int), st));
+                hipLaunchKernelGGL(k_row_norms<false>, dim3((nq + 255) / 256, np), dim3(256), 0, st, tbl, 0, nq, dim, ld, qn, (unsigned int*)nullptr);
+            MIF_HIP(hipMemsetAsync(m->work, 0, 4 * sizeof(unsigned int), st));
             const bool vec = vec_db && vec_q;
+            if (screen) {
+                float* thr = m->thr + (size_t)base * m->max_q;
+                int* ccnt = m->cand_cnt + (size_t)base * m->max_q;
+                int* cand = m->cand + (size_t)base * m->max_q * kCandCap;
+#define MIF_LAUNCH_SCREEN(KK, V, PASS)                                                                           \
+    hipLaunchKernelGGL((k_match_screen<KK, V, PASS>), dim3(m->blocks), dim3(256), 0, st, tbl, np, nq, nd, dim, ld, \
+                       (const float*)qn, (const float*)dn, (const unsigned int*)nmax, thr, ccnt, cand,          \
+                       m->work + 1 + PASS)
+                if (dim <= 64) {
+                    if (vec) { MIF_LAUNCH_SCREEN(64, true, 0); MIF_LAUNCH_SCREEN(64, true, 1); }
+                    else     { MIF_LAUNCH_SCREEN(64, false, 0); MIF_LAUNCH_SCREEN(64, false, 1); }
+                } else {
+                    if (vec) { MIF_LAUNCH_SCREEN(128, true, 0); MIF_LAUNCH_SCREEN(128, true, 1); }
+                    else     { MIF_LAUNCH_SCREEN(128, false, 0); MIF_LAUNCH_SCREEN(128, false, 1); }
+                }
+#undef MIF_LAUNCH_SCREEN
+                if (vec)
+                    hipLaunchKernelGGL(k_match_rank<true>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim,
+                                       ld, (const float*)qn, (const float*)dn, (const int*)ccnt, (const int*)cand, ps, pi,
+                                       nq * 2);
+                else
+                    hipLaunchKernelGGL(k_match_rank<false>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim,
+                                       ld, (const float*)qn, (const float*)dn, (const int*)ccnt, (const int*)cand, ps, pi,
+                                       nq * 2);
+            } else {
 #define MIF_LAUNCH_PARTIAL(KS, V)                                                                              \
     hipLaunchKernelGGL((k_match_partial<KS, V>), dim3(m->blocks), dim3(256), 0, st, tbl, np, nq, nd, dim, ld,    \
                        (const float*)qn, (const float*)dn, nsplit, ps, pi, m->work)
             if (dim <= 64) { if (vec) MIF_LAUNCH_PARTIAL(32, true); else MIF_LAUNCH_PARTIAL(32, false); }
             else           { if (vec) MIF_LAUNCH_PARTIAL(64, true); else MIF_LAUNCH_PARTIAL(64, false); }
 #undef MIF_LAUNCH_PARTIAL
+            }
         }
         if (vec_db && vec_q)
             hipLaunchKernelGGL(k_match_finalize<true>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim,
@@ -688,7 +1037,13 @@ int mif_match_create_batched(int device, int max_query, int max_database, int ma
     if ((e = hipMalloc(&m->dn, P * max_database * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->part_s, P * kMaxSplit * max_query * 2 * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->part_i, P * kMaxSplit * max_query * 2 * sizeof(int))) != hipSuccess) return fail(e);
-    if ((e = hipMalloc(&m->work, sizeof(unsigned int))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&m->work, 4 * sizeof(unsigned int))) != hipSuccess) return fail(e);
+    if (max_pairs >= kScreenMinPairs) {                  // the screening path serves batches only
+        if ((e = hipMalloc(&m->dnmax, P * sizeof(unsigned int))) != hipSuccess) return fail(e);
+        if ((e = hipMalloc(&m->thr, P * max_query * sizeof(float))) != hipSuccess) return fail(e);
+        if ((e = hipMalloc(&m->cand_cnt, P * max_query * sizeof(int))) != hipSuccess) return fail(e);
+        if ((e = hipMalloc(&m->cand, P * max_query * kCandCap * sizeof(int))) != hipSuccess) return fail(e);
+    }
     for (int i = 0; i < kTableSlots; i++) {
         if ((e = hipHostMalloc(&m->h_tbl[i], P * sizeof(mif_match_pair))) != hipSuccess) return fail(e);
         if ((e = hipMalloc(&m->d_tbl[i], P * sizeof(mif_match_pair))) != hipSuccess) return fail(e);
