@@ -172,3 +172,68 @@ def test_more_pairs_than_one_launch_and_table_reuse():
     m = _many_pairs(300, 96, seed=12)
     for call in range(5):
         _many_pairs(7 + 50 * call, 96, seed=20 + call, m=m)
+
+
+def _batch_against_checker(host, cap, dim=128):
+    """Runs all (q, d) pairs of `host` in one batched call with device-side row counts and compares
+    every pair with the checker."""
+    import torch
+    dev = torch.device("cuda:0")
+    P = len(host)
+    Q = torch.zeros((P, cap, 128), dtype=torch.float32, device=dev)
+    D = torch.zeros((P, cap, 128), dtype=torch.float32, device=dev)
+    for p, (q, d) in enumerate(host):
+        Q[p, :len(q)] = torch.from_numpy(q).to(dev)
+        D[p, :len(d)] = torch.from_numpy(d).to(dev)
+    cq = torch.tensor([len(q) for q, _ in host], dtype=torch.int32, device=dev)
+    cd = torch.tensor([len(d) for _, d in host], dtype=torch.int32, device=dev)
+    idx = torch.full((P, cap, 2), -9, dtype=torch.int32, device=dev)
+    dist = torch.zeros((P, cap, 2), dtype=torch.float32, device=dev)
+    m = oda.Matcher(cap, cap, max_pairs=P)
+    pairs = [dict(q=Q[p].data_ptr(), db=D[p].data_ptr(), nq=cq[p:].data_ptr(), nd=cd[p:].data_ptr(),
+                  idx2=idx[p].data_ptr(), dist2=dist[p].data_ptr()) for p in range(P)]
+    m.top2_batch_device(pairs, cap, cap, dim, 128, 0)
+    torch.cuda.synchronize()
+    idx, dist = idx.cpu().numpy(), dist.cpu().numpy()
+    for p, (q, d) in enumerate(host):
+        i_o, d_o = orc.match_top2(np.ascontiguousarray(q[:, :dim]), np.ascontiguousarray(d[:, :dim]))
+        assert np.array_equal(idx[p, :len(q)], i_o), p
+        assert np.array_equal(dist[p, :len(q)].view(np.uint32), d_o.view(np.uint32)), p
+
+
+def test_screened_batches_ties_scales_and_near_ties():
+    """Batches go through the bf16 screening passes; the answer must still be the exact search's.
+    Databases made of a few rows repeated many times (every query has hundreds of rows inside the
+    screening margin: the candidate lists overflow and the query is ranked against all rows, ties go
+    to the lowest index), rows that differ from a query by one unit in one element (far below bf16
+    resolution), values scaled by 1e-3 and 1e3, signed unit-length rows of dimension 64, and
+    dimension 127 of 128."""
+    rng = np.random.RandomState(5)
+    host = []
+    base = sift_like_descriptors(600, seed=77)
+    for p in range(12):
+        q = sift_like_descriptors(300 + 17 * p, seed=200 + p)
+        if p < 4:                                   # few distinct rows, many copies
+            d = np.repeat(base[: 3 + p], 150, axis=0)[rng.permutation(150 * (3 + p))]
+        elif p < 8:                                 # near-ties: copies of queries with one element nudged
+            d = sift_like_descriptors(500, seed=300 + p)
+            for t in range(0, 200):
+                d[t] = q[t % len(q)]
+                d[t, (7 * t) % 128] += 1.0 if t % 3 else 0.0
+        else:
+            d = sift_like_descriptors(450 + p, seed=400 + p)
+        scale = np.float32([1.0, 1e-3, 1e3][p % 3])
+        host.append((np.ascontiguousarray(q * scale), np.ascontiguousarray(d * scale)))
+    _batch_against_checker(host, 960)
+    _batch_against_checker(host, 960, dim=127)
+    surf = []
+    for p in range(10):
+        q = rng.standard_normal((200 + p, 128)).astype(np.float32)
+        d = rng.standard_normal((333 + p, 128)).astype(np.float32)
+        q[:, 64:] = 0
+        d[:, 64:] = 0
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[5] = q[3]
+        surf.append((q, d))
+    _batch_against_checker(surf, 400, dim=64)
