@@ -33,3 +33,11 @@ cd "$ROOT"
 python tools/pmc_traffic.py "$OUT"/pmc_fetch/f_counter_collection.csv "$OUT"/pmc_write/w_counter_collection.csv 64 \
     "$OUT/blur_traffic.json"
 python tools/kstats.py "$OUT/bench_kernel_stats.csv" 7 24
+
+echo "[extra] SQ counters of the extraction and matcher kernels (batch 16)"
+cd /tmp
+timeout -s KILL 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS \
+    --output-format csv -d "$OUT/pmc_sq" -o q -- \
+    python "$ROOT/bench.py" --no-cpu-baseline --batch 16 --steps 2 --warmup 1 > "$OUT/pmc_sq.log" 2>&1
+cd "$ROOT"
+python tools/pmc_summary.py "$OUT"/pmc_sq/q_counter_collection.csv > "$OUT/sq_counters_batch16.txt"
