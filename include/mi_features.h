@@ -138,8 +138,10 @@ int mif_sift_copy_dog(mif_sift* s, int frame, int octave, int index, float* out)
 /* Replaces the _DEBUG probe SIFT::get_gray (SIFT/sift.h:23-26, sift.cpp:1590-1595, 1773-1801): the
  * input of an octave's scale space before any blur, i.e. the gray conversion of the frame (resampled
  * when up_scale is set) for octave 0 and the decimated level 3 of the previous octave otherwise. The
- * reference hands out pyramid level 0, which its blur overwrites in place; here that input has its
- * own buffer. */
+ * reference hands out pyramid level 0, which its blur overwrites in place. Here the extraction
+ * does not store that image (the first blur forms it on the fly), so this call forms it from the
+ * pixels passed to the last extraction call on `s`, which must still be valid when it is a
+ * caller-owned device buffer (mif_sift_enqueue*), resp. from the previous octave's scale space. */
 int mif_sift_copy_base(mif_sift* s, int frame, int octave, float* out);
 /* Gaussian taps of a level as the blur kernels use them (2*radius+1 floats;
  * Build_separable_filter_cof, SIFT/sift.cpp:819-889). Returns the radius. */
@@ -263,7 +265,11 @@ typedef struct mif_match_pair {
 #define MIF_FILTER_RATIO 2
 
 /* npairs independent top-2 searches in one set of launches on `stream`; all
- * pairs share the capacities nq / nd, dim and ld. `pairs` is a host array. */
+ * pairs share the capacities nq / nd, dim and ld. `pairs` is a host array; it is
+ * copied before the call returns (the kernels read a device copy of it). Batches
+ * of 8 pairs or more whose databases are small enough to need no split are first
+ * screened with bf16 matrix instructions and only the rows that can still win are
+ * ranked in fp32; the results are those of the plain search, bit for bit. */
 int mif_match_top2_batch_device(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq, int nd, int dim,
                                 int ld, int filter_mode, void* stream);
 
