@@ -410,21 +410,23 @@ __global__ __launch_bounds__(256) void k_match_partial(PairTable tbl, int npairs
 // follows from the norms (kScreenRel, kScreenAbs). If t is the second smallest s~ of a query, every
 // row among the query's true two nearest has s~ <= t + 2 m: the two rows with the smallest s~ have
 // s <= t + m, so the second smallest s is <= t + m, and a row with s <= t + m has s~ <= t + 2 m.
-//   pass 0: t per query (branch-free running two smallest), threshold = t + 2 m
-//   pass 1: the rows with s~ <= threshold are appended to the query's candidate list
+//   pass 0: t per query and database split (branch-free running two smallest)
+//   pass 1: threshold = smallest t of the query's splits + 2 m; the rows with s~ <= threshold are
+//     appended to the candidate list of (query, split)
 //   k_match_rank: fp32 ranking scores of the candidates, computed exactly as the exact search does
 //     (fmaf chain in ascending k, fmaf(-2, dot, |q|^2 + |d|^2)), two smallest (score, index); a
-//     query whose list overflowed (or holds fewer rows than it must) is ranked against all rows.
+//     list that overflowed stands for all rows of its split, and a query whose lists hold fewer
+//     rows than the answer has is ranked against all rows.
 // The result is therefore the exact search's, bit for bit; the bf16 values only decide which rows
 // are looked at. Same block structure as k_match_partial: 4 waves x 32 queries, database chunks of
 // 64 rows staged in LDS (as bf16, converted while staging), persistent blocks drawing
-// (pair, 128-query tile) items; one item walks all rows of its pair.
+// (pair, database split, 128-query tile) items.
 template <int K, bool VEC, int PASS>
 __global__ __launch_bounds__(256) void k_match_screen(PairTable tbl, int npairs, int nq_cap, int nd_cap, int dim,
                                                       int ld, const float* __restrict__ qn_all,
                                                       const float* __restrict__ dn_all,
-                                                      const unsigned int* __restrict__ dnmax_all,
-                                                      float* __restrict__ thr_all, int* __restrict__ cnt_all,
+                                                      const unsigned int* __restrict__ dnmax_all, int nsplit,
+                                                      float* __restrict__ t2_all, int* __restrict__ cnt_all,
                                                       int* __restrict__ cand_all,
                                                       unsigned int* __restrict__ work_counter)
 {
@@ -452,7 +454,10 @@ __global__ __launch_bounds__(256) void k_match_screen(PairTable tbl, int npairs,
             const int ndz = pz.d_nd ? min(*pz.d_nd, nd_cap) : nd_cap;
             s_rows[z][0] = nqz;
             s_rows[z][1] = ndz;
-            cnt = ndz > 0 ? (nqz + kQT * kWaves - 1) / (kQT * kWaves) : 0;
+            const int chunks = (ndz + kDC - 1) / kDC;
+            const int per = (chunks + nsplit - 1) / nsplit;
+            const int live = per > 0 ? (chunks + per - 1) / per : 0;         // splits that hold rows
+            cnt = ((nqz + kQT * kWaves - 1) / (kQT * kWaves)) * live;
         }
         s_first[z + 1] = cnt;
     }
@@ -503,14 +508,20 @@ __global__ __launch_bounds__(256) void k_match_screen(PairTable tbl, int npairs,
     const float* __restrict__ D = pr.d_db;
     const float* __restrict__ qn = qn_all + (size_t)z * nq_cap;
     const float* __restrict__ dn = dn_all + (size_t)z * nd_cap;
-    float* __restrict__ thr = thr_all + (size_t)z * nq_cap;
-    int* __restrict__ cnt = cnt_all + (size_t)z * nq_cap;
-    int* __restrict__ cand = cand_all + (size_t)z * nq_cap * kCandCap;
     const int nq = __builtin_amdgcn_readfirstlane(s_rows[z][0]);
     const int nd = __builtin_amdgcn_readfirstlane(s_rows[z][1]);
-    const int qbase = (item - s_first[z]) * (kQT * kWaves) + wave * kQT;
+    const int qtiles = (nq + kQT * kWaves - 1) / (kQT * kWaves);
+    const int split = (item - s_first[z]) / qtiles;             // consecutive items share database rows
+    const int qbase = ((item - s_first[z]) - split * qtiles) * (kQT * kWaves) + wave * kQT;
     const int qi = qbase + col;
     const int chunks = (nd + kDC - 1) / kDC;
+    const int per = (chunks + nsplit - 1) / nsplit;
+    const int c_lo = split * per;
+    const int c_hi = min(chunks, c_lo + per);
+    // per (pair, split, query): second smallest score of the split (pass 0), candidate count and list (pass 1)
+    float* __restrict__ t2s = t2_all + (size_t)z * nsplit * nq_cap;
+    int* __restrict__ cnt = cnt_all + ((size_t)z * nsplit + split) * nq_cap;
+    int* __restrict__ cand = cand_all + ((size_t)z * nsplit + split) * nq_cap * kCandCap;
 
     float4 stage[NV];
     float stage_dn = 0.0f;
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(256) void k_match_screen(PairTable tbl, int npairs,
         }
         if (tid < kDC) s_dn[buf][tid] = stage_dn;
     };
-    load_chunk(0);
+    load_chunk(c_lo);
 
     // queries (B operand): lane holds q[qbase + col][16 j + 8 half .. + 7] for every instruction j
     bf16x8 qf[KS];
@@ -561,7 +572,16 @@ __global__ __launch_bounds__(256) void k_match_screen(PairTable tbl, int npairs,
     }
     const float qnv = (qi < nq) ? qn[qi] : 0.0f;
     float t1 = kInf, t2 = kInf;                 // pass 0: the two smallest scores seen
-    const float limit = (PASS == 1 && qi < nq) ? thr[qi] : -kInf;
+    // pass 1: the query's threshold. The second smallest score over all rows is at most the second
+    // smallest of any one split, so the smallest of the splits' values (+ 2 m) keeps every winner.
+    float limit = -kInf;
+    if (PASS == 1 && qi < nq) {
+        float t = kInf;
+        for (int sp = 0; sp * per < chunks; sp++) t = fminf(t, t2s[(size_t)sp * nq_cap + qi]);
+        const float dmax = __builtin_bit_cast(float, dnmax_all[z]);
+        const float m = kScreenRel * __builtin_sqrtf(qnv * dmax) + kScreenAbs * (qnv + dmax);
+        limit = t + 2.0f * m;                   // +inf while no split holds two rows: every row is kept
+    }
     int filled = 0;                             // pass 1: rows appended to the query's list so far
 
     auto consider = [&](const f32x16& acc, int jbase, const float* dnp, bool full) {
@@ -612,7 +632,7 @@ __global__ __launch_bounds__(256) void k_match_screen(PairTable tbl, int npairs,
     auto chunk_step = [&](int c, int buf) {
         store_chunk(buf);
         __syncthreads();
-        load_chunk(min(c + 1, chunks - 1));
+        load_chunk(min(c + 1, c_hi - 1));
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
@@ -629,20 +649,16 @@ __global__ __launch_bounds__(256) void k_match_screen(PairTable tbl, int npairs,
         consider(acc0, c * kDC, &s_dn[buf][0], full);
         consider(acc1, c * kDC + 32, &s_dn[buf][32], full);
     };
-    for (int c = 0; c < chunks; c += 2) {
+    for (int c = c_lo; c < c_hi; c += 2) {
         chunk_step(c, 0);
-        if (c + 1 < chunks) chunk_step(c + 1, 1);
+        if (c + 1 < c_hi) chunk_step(c + 1, 1);
     }
     if (PASS == 0) {
         // lanes l and l + 32 hold the same query (interleaved database rows)
         const float o1 = __shfl_xor(t1, 32), o2 = __shfl_xor(t2, 32);
         t2 = __builtin_amdgcn_fmed3f(t1, t2, o1); t1 = fminf(t1, o1);
         t2 = __builtin_amdgcn_fmed3f(t1, t2, o2); t1 = fminf(t1, o2);
-        if (half == 0 && qi < nq) {
-            const float dmax = __builtin_bit_cast(float, dnmax_all[z]);
-            const float m = kScreenRel * __builtin_sqrtf(qnv * dmax) + kScreenAbs * (qnv + dmax);
-            thr[qi] = t2 + 2.0f * m;            // +inf while fewer than two rows exist: every row is kept
-        }
+        if (half == 0 && qi < nq) t2s[(size_t)split * nq_cap + qi] = t2;
     } else if (half == 0 && qi < nq) {
         cnt[qi] = filled;
     }
@@ -656,7 +672,8 @@ __global__ __launch_bounds__(256) void k_match_screen(PairTable tbl, int npairs,
 template <bool VEC>
 __global__ __launch_bounds__(128) void k_match_rank(PairTable tbl, int nq_cap, int nd_cap, int dim, int ld,
                                                     const float* __restrict__ qn_all, const float* __restrict__ dn_all,
-                                                    const int* __restrict__ cnt_all, const int* __restrict__ cand_all,
+                                                    int nsplit, const int* __restrict__ cnt_all,
+                                                    const int* __restrict__ cand_all,
                                                     float* __restrict__ part_s_all, int* __restrict__ part_i_all,
                                                     int part_stride)
 {
@@ -669,30 +686,45 @@ __global__ __launch_bounds__(128) void k_match_rank(PairTable tbl, int nq_cap, i
     const float* __restrict__ D = pr.d_db;
     const float qnv = qn_all[(size_t)blockIdx.y * nq_cap + i];
     const float* __restrict__ dn = dn_all + (size_t)blockIdx.y * nd_cap;
-    const int* __restrict__ cand = cand_all + ((size_t)blockIdx.y * nq_cap + i) * kCandCap;
-    int n = nd > 0 ? cnt_all[(size_t)blockIdx.y * nq_cap + i] : 0;
-    // a list that overflowed, or that holds fewer rows than the answer has, is not trusted
-    const bool all_rows = n > kCandCap || n < min(2, nd);
-    if (all_rows) n = nd;
+    const int chunks = (nd + kDC - 1) / kDC;
+    const int per = (chunks + nsplit - 1) / nsplit;
     Top2 t;
-    t.s1 = t.s2 = kInf;
-    t.i1 = t.i2 = 0x7fffffff;
     const float* q = Q + (size_t)i * ld;
-    for (int c = 0; c < n; c++) {
-        const int j = all_rows ? c : cand[c];
-        const float* r = D + (size_t)j * ld;
-        float acc = 0.0f;
-        for (int k0 = 0; k0 < dim; k0 += 32) {
-            const int span = min(32, dim - k0);
-            const int avail = min(32, ld - k0);
-            float vq[32], vd[32];
-            load_span<VEC>(q + k0, avail, vq);
-            load_span<VEC>(r + k0, avail, vd);
+    // The lists of the query's splits; a list that overflowed stands for all rows of its split. If the
+    // lists hold fewer rows than the answer has (scores that are not numbers compare false), they are
+    // not trusted and a second round takes every row. One copy of the row loop serves all cases.
+    bool every_row = false;
+    for (;;) {
+        t.s1 = t.s2 = kInf;
+        t.i1 = t.i2 = 0x7fffffff;
+        int listed = 0;
+        for (int sp = 0; sp * per < chunks; sp++) {
+            const size_t at = ((size_t)blockIdx.y * nsplit + sp) * nq_cap + i;
+            const int n = every_row ? kCandCap + 1 : cnt_all[at];
+            listed += n;
+            const bool all = n > kCandCap;
+            const int lo = sp * per * kDC;
+            const int count = all ? min(nd, lo + per * kDC) - lo : n;
+            const int* __restrict__ list = cand_all + at * kCandCap;
+            for (int c = 0; c < count; c++) {
+                const int j = all ? lo + c : list[c];
+                const float* r = D + (size_t)j * ld;
+                float acc = 0.0f;
+                for (int k0 = 0; k0 < dim; k0 += 32) {
+                    const int span = min(32, dim - k0);
+                    const int avail = min(32, ld - k0);
+                    float vq[32], vd[32];
+                    load_span<VEC>(q + k0, avail, vq);
+                    load_span<VEC>(r + k0, avail, vd);
 #pragma unroll
-            for (int k = 0; k < 32; k++)
-                if (k < span) acc = __builtin_fmaf(vd[k], vq[k], acc);
+                    for (int k = 0; k < 32; k++)
+                        if (k < span) acc = __builtin_fmaf(vd[k], vq[k], acc);
+                }
+                top2_insert(t, __builtin_fmaf(-2.0f, acc, qnv + dn[j]), j);
+            }
         }
-        top2_insert(t, __builtin_fmaf(-2.0f, acc, qnv + dn[j]), j);
+        if (every_row || listed >= min(2, nd)) break;
+        every_row = true;
     }
     const size_t o = (size_t)blockIdx.y * part_stride + (size_t)i * 2;
     part_s_all[o] = t.s1; part_s_all[o + 1] = t.s2;
@@ -842,11 +874,13 @@ struct mif_matcher {
     float* d_dist = nullptr;
     float* d_score = nullptr;
     unsigned int* work = nullptr;   // work-item counters: [0] exact search, [1], [2] screening passes
-    // screening: largest database norm per pair, threshold / count / candidates per query
+    // screening: largest database norm per pair; second smallest score / candidate count / candidates
+    // per (pair, split, query), `screen_slots` of them
     unsigned int* dnmax = nullptr;  // [pairs]
-    float* thr = nullptr;           // [pairs][max_q]
-    int* cand_cnt = nullptr;        // [pairs][max_q]
-    int* cand = nullptr;            // [pairs][max_q][kCandCap]
+    float* thr = nullptr;
+    int* cand_cnt = nullptr;
+    int* cand = nullptr;            // [screen_slots][kCandCap]
+    size_t screen_slots = 0;
     // pair tables: pinned host copies and their device twins, used in rotation; a slot is reused
     // once the call that read it last has finished on the GPU (slot_ev)
     mif_match_pair* h_tbl[kTableSlots] = {};
@@ -860,10 +894,10 @@ struct mif_matcher {
 namespace {
 
 constexpr int kMaxSplit = 64;
-// Batches of at least this many pairs whose database needs no split (enough work items without
-// one) go through the bf16 screening passes; single pairs and large databases keep the plain
-// exact search, whose cost does not depend on how many near-ties the data hold.
-constexpr int kScreenMinPairs = 8;
+// Calls with at least this many scores to evaluate go through the bf16 screening passes; below,
+// the two extra launches cost more than the cheaper arithmetic saves.
+constexpr double kScreenMinScores = 3.2e7;
+constexpr int kScreenSplitRows = 32768;     // most rows of a database split under screening
 
 void free_matcher(mif_matcher* m)
 {
@@ -940,7 +974,7 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
         int* pi = m->part_i + (size_t)base * kMaxSplit * m->max_q * 2;
         bool device_counts = false;
         for (int i = 0; i < np; i++) device_counts = device_counts || hp[i].d_nq || hp[i].d_nd;
-        const int nsplit = pick_split(nq, nd, np, device_counts);
+        int nsplit = pick_split(nq, nd, np, device_counts);
         // 16-byte loads of rows need ld % 4 == 0 and 16-byte aligned row starts
         bool vec_db = (ld % 4) == 0, vec_q = (ld % 4) == 0;
         for (int i = 0; i < np; i++) {
@@ -948,7 +982,26 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
             vec_q = vec_q && ((reinterpret_cast<uintptr_t>(hp[i].d_q) & 15u) == 0);
         }
         static const bool no_screen = getenv("MIF_MATCH_NO_SCREEN") != nullptr;      // A/B switch
-        const bool screen = !no_screen && m->cand && np >= kScreenMinPairs && nsplit == 1 && nd >= 2 * kDC;
+        // Screening (k_match_screen): worth its two extra launches from kScreenMinScores scores on (with
+        // device-side row counts the rows present are taken as an eighth of the capacities, as
+        // pick_split does). A candidate list that overflows makes one thread rank all rows of the
+        // list's split, so a split is kept to kScreenSplitRows rows: large databases get more splits
+        // (which also spreads a query's candidates over more lists), and a database that would still
+        // exceed that is searched exactly.
+        bool screen = !no_screen && nd >= 2 * kDC &&
+                      (double)np * nq * nd * (device_counts ? 1.0 / 64.0 : 1.0) >= kScreenMinScores;
+        if (screen) {
+            const int chunks = (nd + kDC - 1) / kDC;
+            int want = nsplit;
+            if (!device_counts) want = std::max(want, (chunks * kDC + kScreenSplitRows / 2 - 1) / (kScreenSplitRows / 2));
+            want = std::min(want, kMaxSplit);
+            const int per = (chunks + want - 1) / want;
+            if ((size_t)per * kDC <= (size_t)kScreenSplitRows &&
+                (size_t)np * want * nq <= m->screen_slots - (size_t)base * m->max_q)
+                nsplit = want;
+            else
+                screen = false;
+        }
         if (nd > 0) {
             unsigned int* nmax = screen ? m->dnmax + base : nullptr;
             if (screen) MIF_HIP(hipMemsetAsync(nmax, 0, (size_t)np * sizeof(unsigned int), st));
@@ -963,12 +1016,12 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
             MIF_HIP(hipMemsetAsync(m->work, 0, 4 * sizeof(unsigned int), st));
             const bool vec = vec_db && vec_q;
             if (screen) {
-                float* thr = m->thr + (size_t)base * m->max_q;
+                float* thr = m->thr + (size_t)base * m->max_q;                    // per (pair, split, query)
                 int* ccnt = m->cand_cnt + (size_t)base * m->max_q;
                 int* cand = m->cand + (size_t)base * m->max_q * kCandCap;
 #define MIF_LAUNCH_SCREEN(KK, V, PASS)                                                                           \
     hipLaunchKernelGGL((k_match_screen<KK, V, PASS>), dim3(m->blocks), dim3(256), 0, st, tbl, np, nq, nd, dim, ld, \
-                       (const float*)qn, (const float*)dn, (const unsigned int*)nmax, thr, ccnt, cand,          \
+                       (const float*)qn, (const float*)dn, (const unsigned int*)nmax, nsplit, thr, ccnt, cand,  \
                        m->work + 1 + PASS)
                 if (dim <= 64) {
                     if (vec) { MIF_LAUNCH_SCREEN(64, true, 0); MIF_LAUNCH_SCREEN(64, true, 1); }
@@ -980,11 +1033,11 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
 #undef MIF_LAUNCH_SCREEN
                 if (vec)
                     hipLaunchKernelGGL(k_match_rank<true>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim,
-                                       ld, (const float*)qn, (const float*)dn, (const int*)ccnt, (const int*)cand, ps, pi,
+                                       ld, (const float*)qn, (const float*)dn, nsplit, (const int*)ccnt, (const int*)cand, ps, pi,
                                        nq * 2);
                 else
                     hipLaunchKernelGGL(k_match_rank<false>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim,
-                                       ld, (const float*)qn, (const float*)dn, (const int*)ccnt, (const int*)cand, ps, pi,
+                                       ld, (const float*)qn, (const float*)dn, nsplit, (const int*)ccnt, (const int*)cand, ps, pi,
                                        nq * 2);
             } else {
 #define MIF_LAUNCH_PARTIAL(KS, V)                                                                              \
@@ -997,10 +1050,10 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
         }
         if (vec_db && vec_q)
             hipLaunchKernelGGL(k_match_finalize<true>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim,
-                               ld, nsplit, (const float*)ps, (const int*)pi);
+                               ld, screen ? 1 : nsplit, (const float*)ps, (const int*)pi);
         else
             hipLaunchKernelGGL(k_match_finalize<false>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim,
-                               ld, nsplit, (const float*)ps, (const int*)pi);
+                               ld, screen ? 1 : nsplit, (const float*)ps, (const int*)pi);
         if (filter_mode != 0)
             hipLaunchKernelGGL(k_match_filter, dim3(np), dim3(256), 0, st, tbl, nq, filter_mode);
     }
@@ -1038,12 +1091,12 @@ int mif_match_create_batched(int device, int max_query, int max_database, int ma
     if ((e = hipMalloc(&m->part_s, P * kMaxSplit * max_query * 2 * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->part_i, P * kMaxSplit * max_query * 2 * sizeof(int))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->work, 4 * sizeof(unsigned int))) != hipSuccess) return fail(e);
-    if (max_pairs >= kScreenMinPairs) {                  // the screening path serves batches only
-        if ((e = hipMalloc(&m->dnmax, P * sizeof(unsigned int))) != hipSuccess) return fail(e);
-        if ((e = hipMalloc(&m->thr, P * max_query * sizeof(float))) != hipSuccess) return fail(e);
-        if ((e = hipMalloc(&m->cand_cnt, P * max_query * sizeof(int))) != hipSuccess) return fail(e);
-        if ((e = hipMalloc(&m->cand, P * max_query * kCandCap * sizeof(int))) != hipSuccess) return fail(e);
-    }
+    // room for a batch without database splits or for one pair with every split
+    m->screen_slots = std::max<size_t>(P, kMaxSplit) * (size_t)max_query;
+    if ((e = hipMalloc(&m->dnmax, P * sizeof(unsigned int))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&m->thr, m->screen_slots * sizeof(float))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&m->cand_cnt, m->screen_slots * sizeof(int))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&m->cand, m->screen_slots * kCandCap * sizeof(int))) != hipSuccess) return fail(e);
     for (int i = 0; i < kTableSlots; i++) {
         if ((e = hipHostMalloc(&m->h_tbl[i], P * sizeof(mif_match_pair))) != hipSuccess) return fail(e);
         if ((e = hipMalloc(&m->d_tbl[i], P * sizeof(mif_match_pair))) != hipSuccess) return fail(e);
