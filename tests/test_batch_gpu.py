@@ -193,3 +193,28 @@ def test_bench_line_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
+
+
+@pytest.mark.parametrize("geom", [(101, 67, 3, 3), (203, 131, 1, 2), (75, 49, 3, 4), (130, 51, 1, 3), (9, 40, 3, 2)])
+def test_odd_sized_batches_against_checker(geom):
+    """Frames of odd sizes back to back (a BGR frame then starts at an odd byte address and its pixels are
+    fetched as unaligned words, the decimation uses its flat indexing): every frame of the batch equals
+    the checker in counts, keypoints, orientations and descriptors."""
+    import torch
+    w, h, c, B = geom
+    frames = [blob_image(w, h, seed=31 * w + h + i, channels=c, shift=(i, 2 * i)) for i in range(B)]
+    px = torch.from_numpy(np.stack(frames)).to(torch.device("cuda:0"))
+    ex = oda.SiftExtractor(w, h, c, batch=B)
+    ex.enqueue(px.data_ptr(), B)
+    for f, img in enumerate(frames):
+        S = orc.SiftOracle(w, h, c)
+        rc_o = S.run(img)
+        rc_g, feat = ex.copy_results(f)
+        assert rc_g == rc_o, f
+        if rc_o != 0:
+            continue
+        kp, octs, ori, des = S.all_features()
+        assert feat.counts == [S.count(o) for o in range(3)], f
+        assert np.array_equal(feat.keypoints.view(np.uint32), kp.view(np.uint32)), f
+        assert np.array_equal(feat.orientations.view(np.uint32), ori.view(np.uint32)), f
+        assert np.array_equal(feat.descriptors.view(np.uint32), des.view(np.uint32)), f
