@@ -6,9 +6,10 @@
 // 1856-1916 extract_features) with one stream-ordered sequence per frame that
 // never returns to the host between stages:
 //
-//   gray | decimate -> 6 x blur_level (H + V + DoG fused, LDS tiled)
-//        -> detect (ballot bitmask + per-row counts) -> scan -> emit (raster order)
-//        -> orientation -> descriptor + normalise
+//   6 x blur_level per octave (H + V in one pass through LDS; level 0 also forms its input,
+//        the gray conversion of the frame resp. the decimated level 3 of the previous octave)
+//        -> detect (extrema of the DoG stack, formed on the fly, as a bitmask; gradient planes)
+//        -> refine -> scan -> emit (raster order) -> orientation -> descriptor + normalise
 //
 // Arithmetic contract: every value is computed with the same sequence of IEEE
 // fp32/fp64 operations on every run and every machine (-ffp-contract=off, fused
