@@ -10,6 +10,20 @@ independent, so ranks process different frames with no data-path collective
 (weak scaling); value = all ranks' frames / max-over-ranks time.
 
 python bench.py --gpus N --steps K --warmup W
+
+With --gpus N > 1 and no WORLD_SIZE in the environment this process only starts N ranks of itself
+(RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one per GPU), forwards rank 0's JSON line and exits
+non-zero if any rank does; under `python -m torch.distributed.run` the ranks exist already and every
+process is a rank.
+
+The one JSON line carries, beside the frames/s headline and its roofline block:
+  matcher             descriptor matches/s of the 1 M x 1 M x 128 search (BASELINE.json configs[4]), exact
+                      fp32 and bf16-screened, against the matrix-core peaks; with N ranks the database rows
+                      are sharded and the top-2 candidates gathered over RCCL by the library itself
+  value_host_to_host  the same step with the frames starting in pinned host memory and the match
+                      summaries ending there (PCIe included; never the headline value)
+  verified            frame 1 of the last timed batch compared with the CPU checker (oracle/): keypoint
+                      counts per octave, good-match count and the matched indices; exit code 1 on mismatch
 """
 import argparse
 import ctypes
@@ -24,24 +38,26 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak
-# Algorithmic bytes of the blur launches per pixel and octave: horizontal blur 6 x (r4 + w4), vertical
-# blur 6 x (r4 + w4) and the base image (gray conversion or decimation, r4 + w4), which the level-0 launch
-# forms while it stages its window = 104 B, spread over the six blur_level launches of an octave. The DoG
-# images (another 40 B in the reference's dataflow) are not part of these launches: they are never stored,
-# the detector subtracts neighbouring levels as it reads them.
-ALG_BYTES_PER_PX_OCTAVE = 104.0
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak
+MFMA_F32_PEAK_TFLOPS = 157.3     # dense fp32 matrix peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak
+# What the reference's dataflow moves for the same launches, per pixel and octave: horizontal blur
+# 6 x (r4 + w4), vertical blur 6 x (r4 + w4) and the base image (gray conversion or decimation, r4 + w4)
+# = 104 B. Reported as `alg_unfused`; the roofline fraction itself uses what the fused launches have to
+# move (min_bytes_per_frame), so that it is a utilisation and stays below 1.
+ALG_UNFUSED_BYTES_PER_PX_OCTAVE = 104.0
+BLUR_TRAFFIC_FILE = os.path.join("profiles", "r02_blur_traffic.json")
 
 
 def min_bytes_per_frame(px, channels):
-    """What the fused blur_level launches have to move at least: r4 + w4 per level, except that level 0
-    reads the frame's bytes (octave 0) or every other pixel of every other row of the previous octave's
-    level 3 (octaves 1, 2: 8 bytes fetched per pixel, memory moves whole sectors)."""
+    """Algorithmic bytes of the blur_level launches of one frame: every level is read once and written
+    once (r4 + w4 per pixel), except that level 0 reads the frame's bytes (octave 0) or every other pixel
+    of every other row of the previous octave's level 3 (octaves 1, 2: 8 bytes fetched per pixel, memory
+    moves whole sectors)."""
     return 44.0 * sum(px) + channels * px[0] + 8.0 * sum(px[1:])
 
 
-
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -56,16 +72,79 @@ def parse_args():
     ap.add_argument("--no-match", action="store_true",
                     help="extraction only (the 4K batch configuration: --width 3840 --height 2160 --channels 1)")
     ap.add_argument("--host-frames", action="store_true",
-                    help="frames start in pinned host memory: every step uploads its batch over PCIe on a copy "
-                         "stream (overlapping the previous batch) and downloads the match summaries; the "
-                         "PCIe-inclusive rate, never the headline value")
+                    help="make the PCIe-inclusive schedule the timed region of the headline fields too (frames "
+                         "start in pinned host memory, summaries end there); for profiling that schedule")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the value_host_to_host measurement")
+    ap.add_argument("--host-steps", type=int, default=5, help="timed steps of the host-to-host leg")
+    ap.add_argument("--match-rows", type=int, default=1000000,
+                    help="query rows = database rows of the matcher block (0 = skip it)")
+    ap.add_argument("--match-steps", type=int, default=2, help="timed passes per form of the matcher block")
+    ap.add_argument("--no-verify", action="store_true", help="skip the comparison with the CPU checker")
     ap.add_argument("--native-pipeline", action="store_true",
                     help="drive the same schedule through the library's own pipeline object (mif_video_*) "
                          "instead of the calls made from this script; no per-stage times in that mode")
     ap.add_argument("--serial", action="store_true",
                     help="run the matcher of a batch after its feature phase instead of beside the next one's")
-    return ap.parse_args()
+    ap.add_argument("--launch-only", action="store_true",
+                    help="start the ranks, form the process group (gloo), report who is there and stop: "
+                         "checks the launcher on a machine without GPUs")
+    return ap.parse_args(argv)
 
+
+# ------------------------------------------------------------------ launcher
+
+def launch_ranks(args, argv):
+    """Parent of an N-rank run: never touches the GPU. Starts N copies of this script, one per GPU,
+    with the environment `torch.distributed.run` would give them; rank 0 prints the JSON line on the
+    stdout they all inherit. Returns the exit code (the first non-zero one, after stopping the rest)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    n = args.gpus
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    live = set(range(n))
+    while live:
+        for r in list(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print("bench.py: rank %d exited with %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                for o in live:
+                    procs[o].terminate()            # exactly the processes started above
+        if live:
+            time.sleep(0.05)
+    return rc
+
+
+def run_launch_only(rank, world, local_rank):
+    """The process group without the GPU work: every rank reports its device index, rank 0 prints them."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    devs = [local_rank]
+    if world > 1:
+        devs = [None] * world
+        dist.all_gather_object(devs, local_rank)
+    if rank == 0:
+        print(json.dumps({"launch_only": True, "n_gpus": world,
+                          "config": {"world_size": dist.get_world_size() if world > 1 else 1,
+                                     "rank_devices": devs}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# -------------------------------------------------------------------- frames
 
 def _frame(job):
     from synth import blob_image
@@ -195,6 +274,15 @@ class Pipeline:
         self.mstream.synchronize()
 
 
+# ------------------------------------------------------- checker-side pieces
+
+def good_rule(d0):
+    """The SIFT good-match rule of common/kpmatch.h:177-202, in double like the reference."""
+    d0 = np.asarray(d0, np.float64)
+    mn = min(100.0, float(d0.min())) if len(d0) else 100.0
+    return d0 <= max(2.5 * mn, 0.35)
+
+
 def cpu_baseline(frames, budget_s, match=True):
     """CPU restatement of the reference's -f 0 path (oracle/, OpenMP) on a bounded sample of the same
     frames: extraction of every sampled frame plus matching against the previous sampled frame."""
@@ -209,8 +297,7 @@ def cpu_baseline(frames, budget_s, match=True):
         des = S.all_features()[3]
         if match and prev is not None and len(des) and len(prev):
             idx, dist = orc.match_top2(oda.pack_sift_rows(des), oda.pack_sift_rows(prev))
-            mn = min(100.0, float(dist[:, 0].min()))
-            _ = dist[:, 0] <= max(2.5 * mn, 0.35)
+            _ = good_rule(dist[:, 0])
         prev = des
         done += 1
         if time.perf_counter() - t0 > budget_s:
@@ -221,6 +308,148 @@ def cpu_baseline(frames, budget_s, match=True):
                       % (done, w, h, "gray" if frames.ndim == 3 else "BGR",
                          "extract + match vs previous frame" if match else "extraction only")}
 
+
+def checker_frame1(frames, match=True):
+    """What the CPU checker gets for frame 1 of the batch (matched against frame 0): per-octave counts,
+    mask of good matches and the nearest database row of every query."""
+    import oracle_lib as orc
+    import object_detection_amd as oda
+    n, h, w = frames.shape[:3]
+    S = orc.SiftOracle(w, h, 1 if frames.ndim == 3 else frames.shape[3])
+    S.run(frames[0])
+    des0 = S.all_features()[3]
+    rc = S.run(frames[1])
+    counts = [S.count(o) for o in range(3)]
+    des1 = S.all_features()[3]
+    out = {"status": rc, "counts": counts}
+    if match and len(des0) and len(des1):
+        idx, dist = orc.match_top2(oda.pack_sift_rows(des1), oda.pack_sift_rows(des0))
+        out["keep"] = good_rule(dist[:, 0])
+        out["idx"] = idx[:, 0]
+    return out
+
+
+def compare_frame1(pipe, want, match=True):
+    """Frame 1 of the batch extracted last against `want` (checker_frame1). Returns (ok, details)."""
+    p = pipe.last()
+    status, counts, _ = pipe.h[p].read_counts(1)
+    det = {"frame": 1, "keypoints": counts, "keypoints_checker": want["counts"]}
+    ok = counts == want["counts"] and status == want["status"]
+    if match and "keep" in want:
+        nq = sum(counts)
+        summ = pipe.summ[p][1].cpu().numpy()
+        good = pipe.good[p][1, :nq].cpu().numpy().astype(bool)
+        idx = pipe.idx[p][1, :nq, 0].cpu().numpy()
+        keep = want["keep"]
+        same_rows = len(keep) == nq
+        det.update(good_matches=int(summ[0]), good_matches_checker=int(keep.sum()))
+        det["match_indices_equal"] = bool(same_rows and np.array_equal(good, keep) and
+                                          np.array_equal(idx[keep], want["idx"][keep]))
+        ok = ok and same_rows and int(summ[0]) == int(keep.sum()) and int(summ[1]) == nq
+        ok = ok and det["match_indices_equal"]
+    det["ok"] = bool(ok)
+    return bool(ok), det
+
+
+# ------------------------------------------------------------ matcher block
+
+def c5_rows(torch, dev, base, rows_lo, rows_hi):
+    """Rows [lo, hi) of the matcher block's database: row j = base row j % len(base), rotated by
+    j // len(base) elements, so that a million distinct SIFT-like rows come from 65536 seeded ones."""
+    nb = base.shape[0]
+    parts = []
+    j = rows_lo
+    while j < rows_hi:
+        r = j // nb
+        end = min(rows_hi, (r + 1) * nb)
+        parts.append(torch.roll(base[j - r * nb:end - r * nb], shifts=r, dims=1))
+        j = end
+    return torch.cat(parts) if parts else torch.empty((0, base.shape[1]), dtype=base.dtype, device=dev)
+
+
+def matcher_block(args, oda, torch, dev, local_rank, rank, world, dist, backend):
+    """BASELINE.json configs[4]: `--match-rows` queries x as many database rows x 128, rows resident in
+    HBM; a pass resolves every query against the whole database. Exact fp32 search and bf16-screened
+    search (same bits) are timed one after the other. With several ranks the database rows are sharded
+    over them and the library gathers the per-shard candidates over RCCL (mif_match_sharded_*)."""
+    from object_detection_amd.distributed import shard_range
+    from synth import sift_like_descriptors
+    n, dim = args.match_rows, 128
+    base = torch.from_numpy(sift_like_descriptors(min(n, 65536), seed=7, dim=dim)).to(dev)
+    lo, hi = shard_range(n, rank, world)
+    db = c5_rows(torch, dev, base, lo, hi)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(7)
+    perm = torch.randperm(n, generator=g).to(dev)           # query i is a noisy copy of database row perm[i]
+    nb = base.shape[0]
+    cols = (torch.arange(dim, device=dev)[None, :] - (perm // nb)[:, None]) % dim
+    q = torch.gather(base[perm % nb], 1, cols)
+    del cols
+    gd = torch.Generator(device=dev)
+    gd.manual_seed(11)
+    q = torch.clamp(q + 8.0 * torch.randn(q.shape, generator=gd, device=dev), 0.0, 255.0).contiguous()
+    idx = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+    dst = torch.zeros((n, 2), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rows = hi - lo
+    if world == 1:
+        m = oda.Matcher(n, max(rows, 1), device=local_rank)
+        pair = [dict(q=q.data_ptr(), db=db.data_ptr(), idx2=idx.data_ptr(), dist2=dst.data_ptr())]
+
+        def search():
+            m.top2_batch_device(pair, n, rows, dim, dim, 0, stream=stream)
+        how = "one GPU holds all rows"
+    else:
+        m = oda.ShardedMatcher.from_process_group(dist, local_rank, max_query=n, max_shard_rows=max(rows, 1))
+
+        def search():
+            m.search(q.data_ptr(), n, db.data_ptr(), rows, lo, dim, dim, idx.data_ptr(), dst.data_ptr(),
+                     stream=stream)
+        how = ("database rows sharded over %d GPUs, top-2 candidates all-gathered over RCCL by the library "
+               "(mif_match_sharded_search)" % world)
+
+    def timed(screening):
+        m.set_screening(screening)
+        search()                                        # warm-up
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.match_steps):
+            search()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = (time.perf_counter() - t0) / args.match_steps
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), idx.clone(), dst.clone()
+
+    dt_exact, idx_e, dst_e = timed(False)
+    dt_scr, idx_s, dst_s = timed(True)
+    flops = 2.0 * dim * float(n) * float(n)
+    same = bool(torch.equal(idx_e, idx_s) and torch.equal(dst_e.view(torch.int32), dst_s.view(torch.int32)))
+    hit = float((idx_s[:, 0].to(torch.int64) == perm).float().mean().item())
+    return {
+        "workload": "%d queries x %d database rows x %d, fp32 rows resident in HBM (BASELINE.json configs[4]); %s"
+                    % (n, n, dim, how),
+        "metric": "descriptor matches/sec", "unit": "matches/s", "n_gpus": world,
+        "scaling": "strong" if world > 1 else None,
+        "value": n / dt_scr, "ms_per_pass": dt_scr * 1e3,
+        "value_exact_fp32": n / dt_exact, "ms_per_pass_exact_fp32": dt_exact * 1e3,
+        "screened_equals_exact": same, "true_neighbour_recovered": hit,
+        "roofline_exact_fp32": {"bound": "mfma", "achieved": flops / dt_exact / 1e12,
+                                "peak": MFMA_F32_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                                "frac": flops / dt_exact / 1e12 / (MFMA_F32_PEAK_TFLOPS * world)},
+        # the screened search runs the contraction twice in bf16 and ranks a few rows per query in fp32
+        "roofline_screened_bf16": {"bound": "mfma", "achieved": 2.0 * flops / dt_scr / 1e12,
+                                   "peak": MFMA_BF16_PEAK_TFLOPS * world, "unit": "TFLOP/s",
+                                   "frac": 2.0 * flops / dt_scr / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world)},
+    }, same
+
+
+# ---------------------------------------------------------------- native leg
 
 def run_native(args, oda, torch, frames, local_rank, world, rank, dist):
     """The timed loop over mif_video_submit_device / mif_video_collect (same schedule, made inside the
@@ -255,11 +484,18 @@ def run_native(args, oda, torch, frames, local_rank, world, rank, dist):
                                      "good_matches_last_frame": res[-1].good_matches}}))
 
 
+# ---------------------------------------------------------------------- main
+
 def main():
-    args = parse_args()
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_only:
+        return run_launch_only(rank, world, local_rank)
     frames_np = make_frames(args.width, args.height, args.batch, rank, args.channels)      # before the GPU is initialised
     import torch
     import object_detection_amd as oda
@@ -271,89 +507,111 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
+    rank_devices = [local_rank]
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, local_rank)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    frames = torch.from_numpy(frames_np).to(torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+
+    def max_over_ranks(dt):
+        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    frames = torch.from_numpy(frames_np).to(device)
     if args.native_pipeline:
         return run_native(args, oda, torch, frames, local_rank, world, rank, dist)
     pipe = Pipeline(oda, torch, local_rank, args.width, args.height, args.batch, serial=args.serial,
                     channels=args.channels, match=not args.no_match)
 
-    if args.host_frames:
-        host = torch.from_numpy(frames_np).pin_memory()
-        dev_buf = [torch.empty_like(frames), frames]
-        ncopy = max(1, min(int(os.environ.get("BENCH_COPY_STREAMS", "4")), args.batch))
-        cstreams = [torch.cuda.Stream(device=frames.device) for _ in range(ncopy)]
-        dstream = torch.cuda.Stream(device=frames.device)
-        cuts = [args.batch * i // ncopy for i in range(ncopy + 1)]
-        host_summ = [torch.empty((args.batch, 2), dtype=torch.int32).pin_memory() for _ in range(2)]
+    def step_resident():
+        pipe.step(frames.data_ptr())
 
-        def step():
-            k = pipe.step_no
-            hk = pipe.h[k % 2]
-            # buffer k % 2 was last read by the scale spaces of batch k - 2, enqueued on this handle's stream
-            # (several copy streams: one DMA engine alone does not fill the link)
-            for ci, cs in enumerate(cstreams):
-                pipe._wait(cs.cuda_stream, hk.stream())
-                with torch.cuda.stream(cs):
-                    dev_buf[k % 2][cuts[ci]:cuts[ci + 1]].copy_(host[cuts[ci]:cuts[ci + 1]], non_blocking=True)
-            for cs in cstreams:
-                pipe._wait(hk.stream(), cs.cuda_stream)
-            pipe.step(dev_buf[k % 2].data_ptr())
-            if k >= 1 and pipe.match and not pipe.serial:
-                # the matcher of batch k - 1 has just been enqueued: its summaries go back to the host
-                pipe._wait(dstream.cuda_stream, pipe.mstream.cuda_stream)
-                with torch.cuda.stream(dstream):
-                    host_summ[(k - 1) % 2].copy_(pipe.summ[(k - 1) % 2], non_blocking=True)
-    else:
-        def step():
-            pipe.step(frames.data_ptr())
+    host_state = {}
 
+    def step_host():
+        """The same step with the batch uploaded from pinned host memory on copy streams (beside the
+        previous batch's work) and the match summaries downloaded to pinned host memory."""
+        if not host_state:
+            ncopy = max(1, min(int(os.environ.get("BENCH_COPY_STREAMS", "4")), args.batch))
+            host_state.update(
+                host=torch.from_numpy(frames_np).pin_memory(),
+                dev_buf=[torch.empty_like(frames), frames],
+                cstreams=[torch.cuda.Stream(device=device) for _ in range(ncopy)],
+                dstream=torch.cuda.Stream(device=device),
+                cuts=[args.batch * i // ncopy for i in range(ncopy + 1)],
+                host_summ=[torch.empty((args.batch, 2), dtype=torch.int32).pin_memory() for _ in range(2)])
+        hs = host_state
+        k = pipe.step_no
+        hk = pipe.h[k % 2]
+        # buffer k % 2 was last read by the scale spaces of batch k - 2, enqueued on this handle's stream
+        # (several copy streams: one DMA engine alone does not fill the link)
+        for ci, cs in enumerate(hs["cstreams"]):
+            pipe._wait(cs.cuda_stream, hk.stream())
+            with torch.cuda.stream(cs):
+                hs["dev_buf"][k % 2][hs["cuts"][ci]:hs["cuts"][ci + 1]].copy_(
+                    hs["host"][hs["cuts"][ci]:hs["cuts"][ci + 1]], non_blocking=True)
+        for cs in hs["cstreams"]:
+            pipe._wait(hk.stream(), cs.cuda_stream)
+        pipe.step(hs["dev_buf"][k % 2].data_ptr())
+        if k >= 1 and pipe.match and not pipe.serial:
+            # the matcher of batch k - 1 has just been enqueued: its summaries go back to the host
+            pipe._wait(hs["dstream"].cuda_stream, pipe.mstream.cuda_stream)
+            with torch.cuda.stream(hs["dstream"]):
+                hs["host_summ"][(k - 1) % 2].copy_(pipe.summ[(k - 1) % 2], non_blocking=True)
+
+    def timed_region(step, warmup, steps):
+        """Barrier + synchronize on both sides of exactly `steps` steps; max over the ranks."""
+        for _ in range(warmup):
+            step()
+        pipe.sync()
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        pipe.sync()
+        torch.cuda.synchronize()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    step = step_host if args.host_frames else step_resident
     for _ in range(args.warmup):
         step()
     pipe.sync()
     for h in pipe.h:
         h.set_timing(True)
-
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    pipe.sync()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-
-    t = torch.tensor([dt], dtype=torch.float64, device=frames.device if backend == "nccl" else "cpu")
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
+    dt_max = timed_region(step, 0, args.steps)
 
     # stage times of the last two batches of the timed region (one per handle), measured with HIP events on
     # the handles' own streams; blur_level is the dominant bandwidth kernel (6 launches per octave)
     timed = [pipe.h[(pipe.last() - i) % len(pipe.h)] for i in range(min(len(pipe.h), args.steps))]
     stage = np.mean([h.stage_times() for h in timed], axis=0)             # ms [octave][stage]
+    for h in pipe.h:
+        h.set_timing(False)
     px = [h_ * w_ for (w_, h_, _) in (pipe.h[0].octave_info(o) for o in range(3))]
     blur_ms = float(stage[:, 1].sum())
-    alg_bytes = ALG_BYTES_PER_PX_OCTAVE * sum(px) * args.batch
-    min_bytes = min_bytes_per_frame(px, args.channels) * args.batch
-    achieved = alg_bytes / (blur_ms * 1e-3) / 1e9
     launches = 18
+    min_bytes = min_bytes_per_frame(px, args.channels) * args.batch
+    unfused_bytes = ALG_UNFUSED_BYTES_PER_PX_OCTAVE * sum(px) * args.batch
+    achieved = min_bytes / (blur_ms * 1e-3) / 1e9
     # HBM-side bytes of the same launches from the PMC passes (FETCH_SIZE and WRITE_SIZE, separate
     # rocprofv3 runs of this script, summarised by tools/pmc_traffic.py); they scale with the frame count
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_blur_traffic.json")) as fh:
+        with open(os.path.join(ROOT, BLUR_TRAFFIC_FILE)) as fh:
             pmc = json.load(fh)
         if args.width == 1920 and args.height == 1080:
             traffic = pmc["blur_bytes_per_frame"] * args.batch / launches
@@ -362,8 +620,29 @@ def main():
     summ = pipe.summ[pipe.last()].cpu().numpy()
     counts = pipe.h[pipe.last()].read_counts(args.batch - 1)
 
+    # the same frames through the CPU checker: frame 1 of the last batch must agree with it
+    verified, verify_detail, want = None, None, None
+    if not args.no_verify and rank == 0 and args.batch >= 2:
+        want = checker_frame1(frames_np, match=not args.no_match)
+        verified, verify_detail = compare_frame1(pipe, want, match=not args.no_match)
+
+    # PCIe-inclusive rate: the same step fed from pinned host memory, summaries back on the host
+    host_leg = None
+    if not args.no_host_leg and not args.host_frames and not args.no_match:
+        dt_host = timed_region(step_host, 2, args.host_steps)
+        frames_host = args.batch * args.host_steps * world
+        host_leg = {"value": frames_host / dt_host, "unit": "frames/s", "steps": args.host_steps,
+                    "ms_per_step": dt_host / args.host_steps * 1e3,
+                    "upload_GBps_per_gpu": args.batch * frames_np[0].nbytes * args.host_steps / dt_host / 1e9,
+                    "window": "pinned host frames -> upload -> extract + match -> match summaries in pinned "
+                              "host memory"}
+        if want is not None:
+            ok_h, _ = compare_frame1(pipe, want, match=True)
+            host_leg["verified"] = ok_h
+            verified = bool(verified and ok_h)
+
     # yardstick measured on this GPU: a 1 GiB device-to-device copy (bytes read + bytes written)
-    src_t = torch.empty(1 << 28, dtype=torch.float32, device=frames.device)
+    src_t = torch.empty(1 << 28, dtype=torch.float32, device=device)
     dst_t = torch.empty_like(src_t)
     dst_t.copy_(src_t)
     torch.cuda.synchronize()
@@ -374,6 +653,17 @@ def main():
     copy_gbs = 5 * 2 * src_t.numel() * 4 / (time.perf_counter() - tc) / 1e9
     del src_t, dst_t
 
+    # the other half of the metric: descriptor matches/s of the big search (the frame pipeline's memory
+    # is released first)
+    match_blk, match_ok = None, True
+    if args.match_rows > 0 and not args.no_match:
+        pipe.sync()
+        del pipe, frames, step, timed
+        host_state.clear()
+        torch.cuda.empty_cache()
+        match_blk, match_ok = matcher_block(args, oda, torch, device, local_rank, rank, world, dist, backend)
+
+    rc = 0
     if rank == 0:
         frames_total = args.batch * args.steps * world
         out = {
@@ -402,27 +692,40 @@ def main():
                        "pipeline": "matcher after each batch" if args.serial else
                                    "matcher of batch k-1 beside the feature phase of batch k",
                        "keypoints_last_frame": counts[1], "good_matches_last_frame": int(summ[-1, 0]),
-                       "parallelism": "frames sharded over %d GPU(s), no collective" % world},
+                       "parallelism": "frames sharded over %d GPU(s), no collective" % world,
+                       "world_size": dist.get_world_size() if dist is not None else 1,
+                       "rank_devices": rank_devices, "backend": backend if dist is not None else None},
             "roofline": {
                 "bound": "hbm", "kernel": "k_blur_level (base image + H + V fused, 18 launches per batch)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": (BLUR_TRAFFIC_FILE + " (separate rocprofv3 --pmc passes of this command)")
+                                  if traffic else None,
                 "avg_launch_us": blur_ms * 1e3 / launches,
-                "alg_bytes_per_launch": alg_bytes / launches,
-                "min_bytes_per_launch": min_bytes / launches,
-                "achieved_min_traffic": achieved * min_bytes / alg_bytes,
+                "alg_bytes_per_launch": min_bytes / launches,
+                "alg_unfused_bytes_per_launch": unfused_bytes / launches,
+                "achieved_alg_unfused": unfused_bytes / (blur_ms * 1e-3) / 1e9,
                 "achieved_traffic": (traffic / (blur_ms * 1e-3 / launches) / 1e9) if traffic else None,
                 "measured_copy_GBps": copy_gbs,
             },
             "stage_ms_per_batch": {"base": float(stage[:, 0].sum()), "scale_space": blur_ms,
                                    "detector": float(stage[:, 2].sum()), "orient_desc": float(stage[:, 3].sum())},
+            "matcher": match_blk,
+            "value_host_to_host": host_leg,
+            "verified": verified,
+            "verify_detail": verify_detail,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_seconds, match=not args.no_match)
         print(json.dumps(out), flush=True)
+        if verified is False or not match_ok:
+            print("bench.py: results differ from the CPU checker or between the two matcher forms", file=sys.stderr)
+            rc = 1
     barrier()
     if dist is not None:
         dist.destroy_process_group()
+    if rc:
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -215,6 +215,10 @@ int mif_match_create(int device, int max_query, int max_database, mif_matcher** 
 /* Same, for up to max_pairs independent (query set, database) pairs per call. */
 int mif_match_create_batched(int device, int max_query, int max_database, int max_pairs, mif_matcher** out);
 int mif_match_destroy(mif_matcher* m);
+/* enable = 0: every call of this matcher runs the plain fp32 search; default 1: large calls are
+ * screened in bf16 first (see mif_match_top2_batch_device). The results are the same bits either
+ * way; the switch exists to measure the two forms side by side. No counterpart in the reference. */
+int mif_match_set_screening(mif_matcher* m, int enable);
 
 /* Exact brute-force 2-nearest-neighbour search in L2; replaces the
  * cv::FlannBasedMatcher::match / knnMatch(k=2) calls of common/kpmatch.h:174-176
@@ -266,10 +270,16 @@ typedef struct mif_match_pair {
 
 /* npairs independent top-2 searches in one set of launches on `stream`; all
  * pairs share the capacities nq / nd, dim and ld. `pairs` is a host array; it is
- * copied before the call returns (the kernels read a device copy of it). Batches
- * of 8 pairs or more whose databases are small enough to need no split are first
- * screened with bf16 matrix instructions and only the rows that can still win are
- * ranked in fp32; the results are those of the plain search, bit for bit. */
+ * copied before the call returns (the kernels read a device copy of it). Calls
+ * with at least 3.2e7 scores to evaluate (npairs * nq * nd; capacities count as an
+ * eighth of themselves when the row counts live on the device) and at least 128
+ * database rows are first screened with bf16 matrix instructions, database splits
+ * of at most 32768 rows each, and only the rows that can still win are ranked in
+ * fp32; a database too large for 64 such splits is searched in fp32 throughout.
+ * Either way the results are those of the plain fp32 search, bit for bit.
+ * A mif_matcher owns one set of work counters and candidate buffers: use it from
+ * one stream at a time (calls on the same stream queue up behind each other; calls
+ * on different streams that may overlap need a matcher each). */
 int mif_match_top2_batch_device(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq, int nd, int dim,
                                 int ld, int filter_mode, void* stream);
 

@@ -58,6 +58,7 @@ SYMBOLS = [
     ("mif_match_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("mif_match_create_batched", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("mif_match_destroy", C.c_int, [_P]),
+    ("mif_match_set_screening", C.c_int, [_P, C.c_int]),
     ("mif_match_top2_batch_device", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("mif_match_top2", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     ("mif_match_top2_scores", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),

@@ -32,12 +32,14 @@ constexpr int kMaxPairs = 256;  // pairs per launch (their item ranges are cache
 constexpr int kTableSlots = 4;  // pair tables in flight per matcher
 constexpr int kCandCap = 32;    // candidates kept per query by the screening passes
 // Screening (see k_match_screen): a bf16 score differs from the fp32 ranking score by at most
-// kScreenRel * |q| * |d| + kScreenAbs * (|q|^2 + |d|^2): two operands rounded to 8 significant bits
-// (2^-9 each), products exact, 128 accumulations in the matrix unit (allowed 2^-22 each), the fp32
-// chain's own 128 roundings, all times the factor 2 of the score and |sum q d| <= |q| |d|:
-// 2 * (2 * 2^-9 + 2^-18 + 128 * 2^-22 + 128 * 2^-24) = 0.0079, rounded up; the absolute term covers
-// the roundings of |q|^2 + |d|^2 and of the final fused multiply-add.
-constexpr float kScreenRel = 0.0085f, kScreenAbs = 1e-6f;
+// kScreenRel * |q| * |d| + kScreenAbs * (|q|^2 + |d|^2). bf16 keeps 8 significant bits, so rounding
+// an operand to nearest moves it by at most 2^-8 of its value; a product of two rounded operands is
+// off by at most (2 * 2^-8 + 2^-16) |q_k d_k| (the products themselves are exact in the matrix unit);
+// the 128 accumulations of the matrix unit are allowed 2^-22 each and the fp32 chain it is compared
+// with has 128 roundings of 2^-24 of its own. With sum |q_k d_k| <= |q| |d| and the factor 2 of the
+// score: 2 * (2 * 2^-8 + 2^-16 + 128 * 2^-22 + 128 * 2^-24) = 0.01573, rounded up. The absolute term
+// covers the roundings of |q|^2 + |d|^2 and of the final fused multiply-add.
+constexpr float kScreenRel = 0.016f, kScreenAbs = 1e-6f;
 
 // The pair table of a call lives in device memory (copied there on the call's stream), so that
 // one launch can serve a whole batch of frame pairs: few launches mean few tails.
@@ -889,6 +891,7 @@ struct mif_matcher {
     bool slot_used[kTableSlots] = {};
     int next_slot = 0;
     int blocks = 512;               // persistent blocks: two per compute unit
+    bool screening = true;          // mif_match_set_screening
 };
 
 namespace {
@@ -988,7 +991,7 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
         // list's split, so a split is kept to kScreenSplitRows rows: large databases get more splits
         // (which also spreads a query's candidates over more lists), and a database that would still
         // exceed that is searched exactly.
-        bool screen = !no_screen && nd >= 2 * kDC &&
+        bool screen = !no_screen && m->screening && nd >= 2 * kDC &&
                       (double)np * nq * nd * (device_counts ? 1.0 / 64.0 : 1.0) >= kScreenMinScores;
         if (screen) {
             const int chunks = (nd + kDC - 1) / kDC;
@@ -1125,6 +1128,13 @@ int mif_match_destroy(mif_matcher* m)
     (void)hipDeviceSynchronize();
     free_matcher(m);
     delete m;
+    return MIF_OK;
+}
+
+int mif_match_set_screening(mif_matcher* m, int enable)
+{
+    if (!m) { mif::set_error("mif_match_set_screening: NULL handle"); return MIF_ERR_INVALID_ARGUMENT; }
+    m->screening = enable != 0;
     return MIF_OK;
 }
 

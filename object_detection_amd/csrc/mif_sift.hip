@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_blur_level(const void* __restrict__ src
         const unsigned boff0 = (SRC == kSrcBgrU8) ? min(px_bytes * (unsigned)cx0, lim) : px_bytes * (unsigned)cx0;
         const unsigned boff1 = (SRC == kSrcBgrU8) ? min(px_bytes * (unsigned)cx1, lim) : px_bytes * (unsigned)cx1;
         const unsigned sh0 = 8u * (3u * (unsigned)cx0 - boff0), sh1 = 8u * (3u * (unsigned)cx1 - boff1);
-        const char* const img0 = src + (SRC == kSrcDecimated ? 4u * (unsigned)(kIntervals * w * 2 * h * 2) : 0u);
+        const char* const img0 = src + (SRC == kSrcDecimated ? (size_t)4 * kIntervals * (size_t)(w * 2) * (size_t)(h * 2) : (size_t)0);
         auto fetch = [&](const char* at) -> float {
             if (SRC == kSrcFloat || SRC == kSrcDecimated) return *(const float*)at;
             uint32_t v;
@@ -1797,13 +1797,27 @@ int mif_sift_snapshot_frame(mif_sift* s, int frame, float* d_descriptors, int32_
 
 int mif_stream_wait_stream(int device, void* waiter, void* signaller)
 {
+    // Events are kept per calling thread and device and used in rotation (a call records one and makes
+    // the waiter wait for that record; a later record of the same event does not change what an
+    // earlier wait waits for), so the steady state creates nothing.
+    constexpr int kDevices = 64, kRing = 16;
+    struct Ring {
+        hipEvent_t ev[kRing] = {};
+        int next = 0;
+    };
+    static thread_local Ring rings[kDevices];
+    if (device < 0 || device >= kDevices) {
+        mif::set_error("mif_stream_wait_stream: device %d out of range", device);
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
     mif::DeviceGuard guard(device);
     if (!guard.ok) { mif::set_error("mif_stream_wait_stream: cannot select device %d", device); return MIF_ERR_HIP; }
-    hipEvent_t ev = nullptr;
-    MIF_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    Ring& r = rings[device];
+    hipEvent_t& ev = r.ev[r.next];
+    r.next = (r.next + 1) % kRing;
+    if (!ev) MIF_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     hipError_t e = hipEventRecord(ev, (hipStream_t)signaller);
     if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
-    (void)hipEventDestroy(ev);      // released once the recorded work has completed
     if (e != hipSuccess) { mif::set_error("mif_stream_wait_stream: %s", hipGetErrorString(e)); return MIF_ERR_HIP; }
     return MIF_OK;
 }

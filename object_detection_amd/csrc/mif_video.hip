@@ -52,7 +52,9 @@ struct mif_video {
     // written while the matcher may still read the one from two batches ago
     float* snap_des[3] = {nullptr, nullptr, nullptr};
     int32_t* snap_cnt[3] = {nullptr, nullptr, nullptr};
-    uint8_t* d_frames[2] = {nullptr, nullptr};  // upload targets of mif_video_submit_host (lazy)
+    uint8_t* d_frames[2] = {nullptr, nullptr};  // upload targets of mif_video_submit_host (allocated on first use)
+    hipEvent_t upload_ev[2] = {nullptr, nullptr};   // end of the last upload into d_frames[i]
+    bool upload_pending[2] = {false, false};
     long long step = 0;                 // batches submitted
     bool matching = true;               // frames are matched against their predecessors
     bool pending = false;               // the last submitted batch has not been matched yet
@@ -79,6 +81,7 @@ void free_all(mif_video* v)
     for (int i = 0; i < 2; i++) {
         (void)hipFree(v->idx[i]); (void)hipFree(v->dist[i]); (void)hipFree(v->good[i]); (void)hipFree(v->summ[i]);
         (void)hipFree(v->d_frames[i]);
+        if (v->upload_ev[i]) (void)hipEventDestroy(v->upload_ev[i]);
         if (v->sift[i]) (void)mif_sift_destroy(v->sift[i]);
     }
     for (int i = 0; i < 3; i++) { (void)hipFree(v->snap_des[i]); (void)hipFree(v->snap_cnt[i]); }
@@ -268,12 +271,22 @@ int mif_video_submit_host(mif_video* v, const uint8_t* frames, int nframes)
     const size_t frame_bytes = (size_t)v->W * v->H * v->C;
     const int slot = (int)(v->step % 2);
     if (!v->d_frames[slot]) MIF_HIP(hipMalloc(&v->d_frames[slot], frame_bytes * v->batch));
+    if (!v->upload_ev[slot]) MIF_HIP(hipEventCreateWithFlags(&v->upload_ev[slot], hipEventDisableTiming));
+    // The caller may rewrite a buffer once the call after next has returned: this is that call for the
+    // buffer handed over two calls ago (same slot), so its upload has to be over before we return.
+    // A copy from pinned memory is asynchronous and nothing else on this path waits on the host.
+    if (v->upload_pending[slot]) {
+        MIF_HIP(hipEventSynchronize(v->upload_ev[slot]));
+        v->upload_pending[slot] = false;
+    }
     // the buffer was last read by the scale spaces of two batches ago, enqueued on this handle's
     // stream; the upload then runs beside the previous batch (asynchronous for pinned memory)
     void* hs = mif_sift_stream(v->sift[slot]);
     int rc = mif_stream_wait_stream(v->device, v->cstream, hs);
     if (rc != MIF_OK) return rc;
     MIF_HIP(hipMemcpyAsync(v->d_frames[slot], frames, frame_bytes * nframes, hipMemcpyHostToDevice, v->cstream));
+    MIF_HIP(hipEventRecord(v->upload_ev[slot], v->cstream));
+    v->upload_pending[slot] = true;
     rc = mif_stream_wait_stream(v->device, hs, v->cstream);
     if (rc != MIF_OK) return rc;
     return submit(v, v->d_frames[slot], nframes);
@@ -293,6 +306,8 @@ int mif_video_collect(mif_video* v, mif_video_frame* out, int capacity, int* n)
         v->pending = false;
     }
     MIF_HIP(hipStreamSynchronize(v->mstream));
+    MIF_HIP(hipStreamSynchronize(v->cstream));   // every upload is over: all host buffers are free again
+    v->upload_pending[0] = v->upload_pending[1] = false;
     int total = 0;
     for (const auto& r : v->inflight) total += r.nframes;
     if (total > capacity) {

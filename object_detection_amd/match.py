@@ -26,6 +26,10 @@ class Matcher:
     def __del__(self):
         self.close()
 
+    def set_screening(self, enable=True):
+        """False: plain fp32 search for every call (same results; for measurements)."""
+        _lib.check(self._lib.mif_match_set_screening(self._h, 1 if enable else 0))
+
     def top2(self, q, db, dim=None, return_scores=False):
         """q [nq, ld], db [nd, ld] float32 host arrays; only the first `dim` columns take part.
         Returns idx [nq, 2] int32 (-1 = missing) and dist [nq, 2] float32 (inf = missing); with
@@ -90,7 +94,7 @@ def match_sift_features(matcher, desc_object, desc_scene):
     if len(d0):
         min_dist = min(min_dist, float(d0.min()))
         max_dist = max(max_dist, float(d0.max()))
-    keep = dist[:, 0] <= max(2.5 * min_dist, 0.35)
+    keep = d0 <= max(2.5 * min_dist, 0.35)          # in double, as kpmatch.h:198 compares
     qi = np.nonzero(keep)[0].astype(np.int32)
     return np.stack([qi, idx[keep, 0]], axis=1), dist[keep, 0], min_dist, max_dist
 

@@ -106,3 +106,33 @@ def test_shard_range_and_merge_unit():
     dists = torch.tensor([[[1.7, inf]], [[inf, inf]]])
     wi, wd = merge_top2(scores, idx, dists)
     assert wi.tolist() == [[2, -1]] and wd[0, 0] == 1.7 and torch.isinf(wd[0, 1])
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`bench.py --gpus N` without a launcher around it starts N ranks itself (launch-only mode: the
+    process group forms over gloo, no GPU work) and rank 0 reports the world it saw."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    for n in (1, 2, 3):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--launch-only"],
+                             env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout
+        rec = json.loads(lines[0])
+        assert rec["n_gpus"] == n and rec["config"]["world_size"] == n
+        assert rec["config"]["rank_devices"] == list(range(n))
+
+
+def test_bench_launcher_reports_a_failing_rank():
+    """A rank that dies makes the parent stop the others and exit non-zero."""
+    import subprocess
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without GPUs: there the ranks of a real run stop at once")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    # without a GPU every rank of a real run stops with "bench.py needs a GPU"; tiny frames keep it quick
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2",
+                          "--width", "64", "--height", "48"], env=env, capture_output=True, text=True, timeout=180)
+    assert out.returncode != 0
+    assert "needs a GPU" in out.stderr
