@@ -237,3 +237,70 @@ def test_screened_batches_ties_scales_and_near_ties():
         d[5] = q[3]
         surf.append((q, d))
     _batch_against_checker(surf, 400, dim=64)
+
+
+def _adversarial_pair(nq, nd, e, seed):
+    """Queries and rows placed on the half-way points of bf16 rounding so that the bf16 score of the
+    true nearest row X is as much too large, and those of the runners-up A, B as much too small, as
+    rounding to 8 significant bits allows: the query rounds down on the elements X lives on and up on
+    the elements A and B live on. A screening margin below the true bound drops X (with 0.0085 |q| |d|
+    in place of 0.016 |q| |d| every one of these queries loses its nearest row). `e` scales
+    everything by a power of two (same rounding pattern at another exponent)."""
+    rng = np.random.RandomState(seed)
+    sc = np.float32(2.0 ** e)
+    q = np.zeros((nq, 128), np.float32)
+    d = (rng.uniform(0.0, 10.0, (nd, 128)) * sc).astype(np.float32)        # far away filler rows
+    lo_v, hi_v = np.float32(128.49) * sc, np.float32(128.51) * sc         # round to 128 and 129 (x 2^e)
+    want = np.zeros(nq, np.int64)
+    first = rng.permutation(128)[:64]                                      # the elements X lives on
+    second = np.setdiff1d(np.arange(128), first)
+    for i in range(nq):
+        # every query has its own random signs (rounding is symmetric in the sign), which puts the rows
+        # built for the other queries far away from it
+        sg = rng.choice(np.float32([-1.0, 1.0]), 128)
+        q[i, first], q[i, second] = lo_v, hi_v
+        q[i] *= sg
+        x, a, b = [3 * i + int(v) for v in rng.permutation(3)]
+        d[[x, a, b]] = 0
+        d[x, first] = lo_v * sg[first]
+        d[a, second] = hi_v * sg[second]
+        d[b, second] = hi_v * sg[second]
+        d[a, first[0]] = d[b, first[0]] = np.float32(-2.0) * sc * sg[first[0]]   # A, B slightly farther than X
+        want[i] = x
+    return q, d, want
+
+
+def test_screening_margin_against_adversarial_rounding():
+    """Rows on bf16 rounding boundaries (see _adversarial_pair): the screened search must still return
+    the plain fp32 search's answer, which is the checker's."""
+    import torch
+    dev = torch.device("cuda:0")
+    P, nq, nd = 10, 600, 2000
+    cap_q, cap_d = 2000, 2000
+    host = [_adversarial_pair(nq, nd, e, seed=900 + e) for e in (-9, -4, -1, 0, 0, 1, 2, 5, 8, 12)]
+    Q = torch.zeros((P, cap_q, 128), dtype=torch.float32, device=dev)
+    D = torch.zeros((P, cap_d, 128), dtype=torch.float32, device=dev)
+    for p, (q, d, _) in enumerate(host):
+        Q[p, :nq] = torch.from_numpy(q).to(dev)
+        D[p, :nd] = torch.from_numpy(d).to(dev)
+    res = []
+    for screening in (True, False):
+        idx = torch.full((P, cap_q, 2), -9, dtype=torch.int32, device=dev)
+        dist = torch.zeros((P, cap_q, 2), dtype=torch.float32, device=dev)
+        m = oda.Matcher(cap_q, cap_d, max_pairs=P)
+        m.set_screening(screening)
+        # row counts passed by value: with counts in device memory the call would assume an eighth of the
+        # capacities and stay below the screening threshold (10 x 2000 x 2000 scores are above it); the
+        # query rows past nq are zeros and their results are ignored
+        pairs = [dict(q=Q[p].data_ptr(), db=D[p].data_ptr(), idx2=idx[p].data_ptr(), dist2=dist[p].data_ptr())
+                 for p in range(P)]
+        m.top2_batch_device(pairs, cap_q, nd, 128, 128, 0)
+        torch.cuda.synchronize()
+        res.append((idx.cpu().numpy()[:, :nq], dist.cpu().numpy()[:, :nq]))
+    (i_s, d_s), (i_e, d_e) = res
+    assert np.array_equal(i_s, i_e) and np.array_equal(d_s.view(np.uint32), d_e.view(np.uint32))
+    for p, (q, d, want) in enumerate(host):
+        i_o, d_o = orc.match_top2(q, d)
+        assert np.array_equal(i_s[p], i_o), p
+        assert np.array_equal(d_s[p].view(np.uint32), d_o.view(np.uint32)), p
+        assert np.array_equal(i_o[:, 0], want), p       # the construction holds: X is the true nearest row
