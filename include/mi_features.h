@@ -243,6 +243,21 @@ int mif_match_top2_device(mif_matcher* m, const float* d_q, int nq, const int32_
                           int nd, const int32_t* d_nd, int dim, int ld, int32_t* d_idx2, float* d_dist2,
                           void* stream);
 
+/* The same search as mif_match_top2_device for callers that cannot allocate: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc. No counterpart in the reference.
+ * There is no handle: the workspace (pair table, work counters, row norms, per-split partial winners)
+ * is one fixed array of 4.3 MB in device memory that every GPU the library runs on holds until the
+ * process ends, so a call is limited to MIF_NOALLOC_MAX_QUERY query rows and
+ * MIF_NOALLOC_MAX_DATABASE database rows (MIF_ERR_CAPACITY beyond; use a mif_matcher then). The call
+ * enqueues kernels and one memset on `stream` (a hipStream_t of `device`, NULL = default) and calls no
+ * hipMalloc / hipFree or allocating library routine; the first call on a device looks the array's
+ * address up. Always the plain fp32 search; results are the bits mif_match_top2_device returns.
+ * All calls on one GPU share the array: calls that may overlap on one GPU (different streams, different
+ * threads) race and must be serialised by the caller. */
+#define MIF_NOALLOC_MAX_QUERY 4096
+#define MIF_NOALLOC_MAX_DATABASE 65536
+int mif_match_top2_device_noalloc(int device, const float* d_q, int nq, const float* d_db, int nd, int dim, int ld,
+                                  int32_t* d_idx2, float* d_dist2, void* stream);
 
 /* One (query set, database) pair of a batched match; every pointer is a device
  * address. d_nq / d_nd may be NULL (the call's nq / nd are then the row counts).

@@ -63,6 +63,7 @@ SYMBOLS = [
     ("mif_match_top2", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     ("mif_match_top2_scores", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     ("mif_match_top2_device", C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P]),
+    ("mif_match_top2_device_noalloc", C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     ("mif_video_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("mif_video_destroy", C.c_int, [_P]),
     ("mif_video_batch", C.c_int, [_P]),

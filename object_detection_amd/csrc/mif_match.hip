@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
 #include "mif_common.h"
 
 namespace {
@@ -1065,9 +1066,131 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
     return MIF_OK;
 }
 
+// ------------------------------------------------------- search without allocations
+//
+// mif_match_top2_device_noalloc: the exact search (k_row_norms, k_match_partial, k_match_finalize)
+// for callers that cannot allocate. Everything a matcher handle would own lives in one fixed array in
+// device memory: the pair table the kernels read, the work-item counters, the row norms and the
+// per-split partial winners. Every GPU holds its own copy of the array at its own address; the
+// address is asked for once per device (first call there) and kept.
+constexpr int kNaMaxQuery = MIF_NOALLOC_MAX_QUERY;
+constexpr int kNaMaxDatabase = MIF_NOALLOC_MAX_DATABASE;
+constexpr size_t kNaOffTable = 0;                                                  // one mif_match_pair
+constexpr size_t kNaOffWork = 256;                                                 // 4 counters
+constexpr size_t kNaOffQn = 512;                                                   // float[max query]
+constexpr size_t kNaOffDn = kNaOffQn + sizeof(float) * kNaMaxQuery;                // float[max database]
+constexpr size_t kNaOffPartS = kNaOffDn + sizeof(float) * kNaMaxDatabase;          // float[splits][max query][2]
+constexpr size_t kNaOffPartI = kNaOffPartS + sizeof(float) * 2 * kMaxSplit * kNaMaxQuery;
+constexpr size_t kNaBytes = kNaOffPartI + sizeof(int) * 2 * kMaxSplit * kNaMaxQuery;
+static_assert(sizeof(mif_match_pair) <= 256, "the pair table slot is 256 bytes");
+static_assert(kNaOffDn % 256 == 0 && kNaOffPartS % 256 == 0 && kNaOffPartI % 256 == 0, "sub-buffers stay aligned");
+static_assert(kNaBytes <= (size_t)8 << 20, "the fixed array is meant to stay small");
+
+static __device__ __align__(256) unsigned char scratch[kNaBytes];
+
+constexpr int kNaDevices = 64;
+unsigned char* g_na_ptr[kNaDevices] = {};       // device address of `scratch` on every GPU seen so far
+std::mutex g_na_mutex;
+
+// Device address of this GPU's copy of the array; `device` is current.
+int noalloc_scratch(int device, unsigned char** out)
+{
+    std::lock_guard<std::mutex> lock(g_na_mutex);
+    if (!g_na_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            mif::set_error("mif_match_top2_device_noalloc: hipGetSymbolAddress failed on device %d: %s", device,
+                           hipGetErrorString(e));
+            return MIF_ERR_HIP;
+        }
+        g_na_ptr[device] = static_cast<unsigned char*>(p);
+    }
+    *out = g_na_ptr[device];
+    return MIF_OK;
+}
+
+// The one-entry pair table is written by a kernel (the pair travels as a kernel argument), so that no
+// host buffer has to be staged.
+__global__ void k_write_pair(mif_match_pair* tbl, mif_match_pair pr) { *tbl = pr; }
+
 } // namespace
 
 extern "C" {
+
+int mif_match_top2_device_noalloc(int device, const float* d_q, int nq, const float* d_db, int nd, int dim, int ld,
+                                  int32_t* d_idx2, float* d_dist2, void* stream)
+{
+    if (device < 0 || device >= kNaDevices) {
+        mif::set_error("mif_match_top2_device_noalloc: device %d out of range", device);
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    if (!d_idx2 || !d_dist2 || (nq > 0 && !d_q) || (nd > 0 && !d_db)) {
+        mif::set_error("mif_match_top2_device_noalloc: NULL argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    if (nq < 0 || nd < 0 || nq > kNaMaxQuery || nd > kNaMaxDatabase) {
+        mif::set_error("mif_match_top2_device_noalloc: %d x %d rows exceed the fixed workspace of %d x %d rows "
+                       "(use a mif_matcher for larger searches)", nq, nd, kNaMaxQuery, kNaMaxDatabase);
+        return MIF_ERR_CAPACITY;
+    }
+    if (dim < 1 || dim > 128 || ld < dim) {
+        mif::set_error("match: dim must be 1..128 and ld >= dim (got dim %d, ld %d)", dim, ld);
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    if (nq == 0) return MIF_OK;
+    mif::DeviceGuard guard(device);
+    if (!guard.ok) { mif::set_error("mif_match_top2_device_noalloc: cannot select device %d", device); return MIF_ERR_HIP; }
+    unsigned char* base = nullptr;
+    const int rc = noalloc_scratch(device, &base);
+    if (rc != MIF_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    mif_match_pair* tbl = reinterpret_cast<mif_match_pair*>(base + kNaOffTable);
+    unsigned int* work = reinterpret_cast<unsigned int*>(base + kNaOffWork);
+    float* qn = reinterpret_cast<float*>(base + kNaOffQn);
+    float* dn = reinterpret_cast<float*>(base + kNaOffDn);
+    float* ps = reinterpret_cast<float*>(base + kNaOffPartS);
+    int* pi = reinterpret_cast<int*>(base + kNaOffPartI);
+    mif_match_pair pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.d_q = d_q; pr.d_db = d_db; pr.d_idx2 = d_idx2; pr.d_dist2 = d_dist2;
+    hipLaunchKernelGGL(k_write_pair, dim3(1), dim3(1), 0, st, tbl, pr);
+    const int nsplit = pick_split(nq, nd, 1, false);
+    const bool vec_db = (ld % 4) == 0 && (reinterpret_cast<uintptr_t>(d_db) & 15u) == 0;
+    const bool vec_q = (ld % 4) == 0 && (reinterpret_cast<uintptr_t>(d_q) & 15u) == 0;
+    const bool vec = vec_db && vec_q;
+    int blocks = 512;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+        blocks = 2 * cus;
+    if (nd > 0) {
+        // the counters of the last call are stale: they start from zero; norms and partial winners are
+        // written before they are read for every row and split this call uses
+        MIF_HIP(hipMemsetAsync(work, 0, 4 * sizeof(unsigned int), st));
+        if (vec_db)
+            hipLaunchKernelGGL(k_row_norms<true>, dim3((nd + 255) / 256, 1), dim3(256), 0, st, (PairTable)tbl, 1, nd, dim, ld, dn, (unsigned int*)nullptr);
+        else
+            hipLaunchKernelGGL(k_row_norms<false>, dim3((nd + 255) / 256, 1), dim3(256), 0, st, (PairTable)tbl, 1, nd, dim, ld, dn, (unsigned int*)nullptr);
+        if (vec_q)
+            hipLaunchKernelGGL(k_row_norms<true>, dim3((nq + 255) / 256, 1), dim3(256), 0, st, (PairTable)tbl, 0, nq, dim, ld, qn, (unsigned int*)nullptr);
+        else
+            hipLaunchKernelGGL(k_row_norms<false>, dim3((nq + 255) / 256, 1), dim3(256), 0, st, (PairTable)tbl, 0, nq, dim, ld, qn, (unsigned int*)nullptr);
+#define MIF_LAUNCH_PARTIAL(KS, V)                                                                              \
+    hipLaunchKernelGGL((k_match_partial<KS, V>), dim3(blocks), dim3(256), 0, st, (PairTable)tbl, 1, nq, nd, dim, ld, \
+                       (const float*)qn, (const float*)dn, nsplit, ps, pi, work)
+        if (dim <= 64) { if (vec) MIF_LAUNCH_PARTIAL(32, true); else MIF_LAUNCH_PARTIAL(32, false); }
+        else           { if (vec) MIF_LAUNCH_PARTIAL(64, true); else MIF_LAUNCH_PARTIAL(64, false); }
+#undef MIF_LAUNCH_PARTIAL
+    }
+    if (vec)
+        hipLaunchKernelGGL(k_match_finalize<true>, dim3((nq + 127) / 128, 1), dim3(128), 0, st, (PairTable)tbl, nq, nd, dim,
+                           ld, nsplit, (const float*)ps, (const int*)pi);
+    else
+        hipLaunchKernelGGL(k_match_finalize<false>, dim3((nq + 127) / 128, 1), dim3(128), 0, st, (PairTable)tbl, nq, nd, dim,
+                           ld, nsplit, (const float*)ps, (const int*)pi);
+    MIF_HIP(hipGetLastError());
+    return MIF_OK;
+}
 
 int mif_match_create_batched(int device, int max_query, int max_database, int max_pairs, mif_matcher** out)
 {
