@@ -79,6 +79,8 @@ def parse_args(argv=None):
     ap.add_argument("--match-rows", type=int, default=1000000,
                     help="query rows = database rows of the matcher block (0 = skip it)")
     ap.add_argument("--match-steps", type=int, default=2, help="timed passes per form of the matcher block")
+    ap.add_argument("--match-timeout", type=int, default=300,
+                    help="seconds after which a multi-rank matcher block is given up (the line is printed without it)")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison with the CPU checker")
     ap.add_argument("--native-pipeline", action="store_true",
                     help="drive the same schedule through the library's own pipeline object (mif_video_*) "
@@ -653,16 +655,8 @@ def main():
     copy_gbs = 5 * 2 * src_t.numel() * 4 / (time.perf_counter() - tc) / 1e9
     del src_t, dst_t
 
-    # the other half of the metric: descriptor matches/s of the big search (the frame pipeline's memory
-    # is released first)
-    match_blk, match_ok = None, True
-    if args.match_rows > 0 and not args.no_match:
-        pipe.sync()
-        del pipe, frames, step, timed
-        host_state.clear()
-        torch.cuda.empty_cache()
-        match_blk, match_ok = matcher_block(args, oda, torch, device, local_rank, rank, world, dist, backend)
-
+    keypoints_last, good_last = counts[1], int(summ[-1, 0])
+    world_seen = dist.get_world_size() if dist is not None else 1
     rc = 0
     if rank == 0:
         frames_total = args.batch * args.steps * world
@@ -691,9 +685,9 @@ def main():
                        "frames_per_step": args.batch, "octaves": 3, "levels": 6,
                        "pipeline": "matcher after each batch" if args.serial else
                                    "matcher of batch k-1 beside the feature phase of batch k",
-                       "keypoints_last_frame": counts[1], "good_matches_last_frame": int(summ[-1, 0]),
+                       "keypoints_last_frame": keypoints_last, "good_matches_last_frame": good_last,
                        "parallelism": "frames sharded over %d GPU(s), no collective" % world,
-                       "world_size": dist.get_world_size() if dist is not None else 1,
+                       "world_size": world_seen,
                        "rank_devices": rank_devices, "backend": backend if dist is not None else None},
             "roofline": {
                 "bound": "hbm", "kernel": "k_blur_level (base image + H + V fused, 18 launches per batch)",
@@ -710,11 +704,51 @@ def main():
             },
             "stage_ms_per_batch": {"base": float(stage[:, 0].sum()), "scale_space": blur_ms,
                                    "detector": float(stage[:, 2].sum()), "orient_desc": float(stage[:, 3].sum())},
-            "matcher": match_blk,
+            "matcher": None,
             "value_host_to_host": host_leg,
             "verified": verified,
             "verify_detail": verify_detail,
         }
+    else:
+        out = None
+
+    # The other half of the metric: descriptor matches/s of the big search (the frame pipeline's memory is
+    # released first). With several ranks the block contains the library's own RCCL collective; should that
+    # ever stall, a watchdog on every rank ends the run with the line as it stands rather than hanging it.
+    match_ok = True
+    if args.match_rows > 0 and not args.no_match:
+        pipe.sync()
+        del pipe, frames, step, timed
+        host_state.clear()
+        torch.cuda.empty_cache()
+        if world > 1 and backend != "nccl":
+            blk = {"skipped": "rehearsal with ranks sharing a GPU: RCCL needs one GPU per rank"}
+        else:
+            import threading
+
+            def give_up():
+                if rank == 0:
+                    out["matcher"] = {"error": "the sharded search did not finish within %d s" % args.match_timeout}
+                    print(json.dumps(out), flush=True)
+                os._exit(0 if rank == 0 else 3)
+
+            dog = threading.Timer(args.match_timeout, give_up) if world > 1 else None
+            if dog is not None:
+                dog.daemon = True
+                dog.start()
+            try:
+                blk, match_ok = matcher_block(args, oda, torch, device, local_rank, rank, world, dist, backend)
+            except Exception as exc:                      # reported in the line; the headline stands
+                if world == 1:
+                    raise
+                blk, match_ok = {"error": repr(exc)}, True
+            if dog is not None:
+                dog.cancel()
+        if rank == 0:
+            out["matcher"] = blk
+
+    rc = 0
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_seconds, match=not args.no_match)
         print(json.dumps(out), flush=True)

@@ -298,6 +298,58 @@ typedef struct mif_match_pair {
 int mif_match_top2_batch_device(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq, int nd, int dim,
                                 int ld, int filter_mode, void* stream);
 
+/* --------------------------------------------- database sharded over GPUs -- */
+
+/* A descriptor database split row-wise over several GPUs. Every GPU searches its rows
+ * (mif_match_top2_batch_device), the per-shard winners (ranking score, global row index, distance:
+ * 24 bytes per query and shard) are exchanged with ONE RCCL all-gather over xGMI, and every GPU merges
+ * them on (score, index), so that every rank ends up with the result of one search over the whole
+ * database, bit for bit. The reference has no counterpart (its matcher is the single FLANN call of
+ * common/kpmatch.h:174-176, 284-286; its only split is the CPU/GPU NDRange split of
+ * clDriver.h:1879-1921); this serves the same call sites for databases that do not fit, or should not
+ * wait for, one GPU.
+ *
+ * A handle drives `nlocal` consecutive ranks first_rank .. first_rank + nlocal - 1 of `nranks` from the
+ * calling process, rank first_rank + i on GPU devices[i]:
+ *   - one process per GPU: nlocal = 1; one rank calls mif_match_sharded_unique_id, hands the
+ *     MIF_SHARD_ID_BYTES bytes to the others by its own means (MPI, a socket, torch.distributed) and all
+ *     call mif_match_sharded_create with it (a collective call: it returns when all ranks have joined);
+ *   - one process for all GPUs of a node: nlocal = nranks, id may be NULL; the RCCL calls of the shards
+ *     are fused in one group.
+ * Shards that share a GPU (only when nlocal = nranks; RCCL cannot place two ranks on one GPU) exchange
+ * their messages with device-to-device copies instead of RCCL: the form for machines with one GPU.
+ * RCCL is loaded (dlopen of librccl.so.1) by the first of these calls that needs it; MIF_ERR_UNSUPPORTED
+ * when it is not installed. */
+typedef struct mif_match_sharded mif_match_sharded;
+#define MIF_SHARD_ID_BYTES 128
+int mif_match_sharded_unique_id(void* id /* [MIF_SHARD_ID_BYTES] */);
+int mif_match_sharded_create(const int* devices, int nlocal, int first_rank, int nranks, const void* id,
+                             int max_query, int max_shard_rows, mif_match_sharded** out);
+int mif_match_sharded_destroy(mif_match_sharded* h);
+/* nlocal, nranks and whether the exchange runs over RCCL (1) or device copies (0); any pointer may be NULL. */
+int mif_match_sharded_ranks(const mif_match_sharded* h, int* nlocal, int* nranks, int* uses_rccl);
+/* mif_match_set_screening for every shard's matcher. */
+int mif_match_sharded_set_screening(mif_match_sharded* h, int enable);
+
+/* What one local rank brings to a search; all pointers are device addresses on that rank's GPU. */
+typedef struct mif_shard_io {
+    const float* d_q;      /* [nq][ld] the queries (the same rows on every rank) */
+    const float* d_shard;  /* [shard_rows][ld] this rank's database rows */
+    int32_t shard_rows;
+    int32_t global_offset; /* index of the shard's first row in the whole database */
+    int32_t* d_idx2;       /* [nq][2] out: GLOBAL row indices of the two nearest rows, -1 when missing */
+    float* d_dist2;        /* [nq][2] out: their Euclidean distances, +inf when missing */
+    void* stream;          /* hipStream_t to enqueue on; NULL = a stream the handle owns for this rank
+                            * (mif_match_sharded_sync waits for those). Keep one stream per rank from call
+                            * to call: the handle's buffers are reused in stream order. */
+} mif_shard_io;
+
+/* One search: io[i] belongs to local rank i. nq, dim and ld must be the same on every rank of the
+ * communicator and every rank must make the call (it contains a collective). Everything is enqueued;
+ * nothing waits on the host. */
+int mif_match_sharded_search(mif_match_sharded* h, const mif_shard_io* io, int nq, int dim, int ld);
+int mif_match_sharded_sync(mif_match_sharded* h);
+
 /* ------------------------------------------------------- frame sequences -- */
 
 /* The -v loop of SIFT/main.cpp:103-153 (one extract_features call per frame, the previous

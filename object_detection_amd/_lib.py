@@ -64,6 +64,13 @@ SYMBOLS = [
     ("mif_match_top2_scores", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     ("mif_match_top2_device", C.c_int, [_P, _P, C.c_int, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P, _P, _P]),
     ("mif_match_top2_device_noalloc", C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    ("mif_match_sharded_unique_id", C.c_int, [_P]),
+    ("mif_match_sharded_create", C.c_int, [_PI, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("mif_match_sharded_destroy", C.c_int, [_P]),
+    ("mif_match_sharded_ranks", C.c_int, [_P, _PI, _PI, _PI]),
+    ("mif_match_sharded_set_screening", C.c_int, [_P, C.c_int]),
+    ("mif_match_sharded_search", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
+    ("mif_match_sharded_sync", C.c_int, [_P]),
     ("mif_video_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("mif_video_destroy", C.c_int, [_P]),
     ("mif_video_batch", C.c_int, [_P]),
@@ -86,6 +93,13 @@ class MatchPair(C.Structure):
                 ("d_good", _P), ("d_summary", _P), ("d_minmax", _P), ("d_score2", _P)]
 
 
+class ShardIO(C.Structure):
+    """mif_shard_io of include/mi_features.h."""
+    _fields_ = [("d_q", _P), ("d_shard", _P), ("shard_rows", C.c_int32), ("global_offset", C.c_int32),
+                ("d_idx2", _P), ("d_dist2", _P), ("stream", _P)]
+
+
+SHARD_ID_BYTES = 128
 FILTER_NONE, FILTER_SIFT, FILTER_RATIO = 0, 1, 2
 
 

@@ -72,6 +72,77 @@ class Matcher:
                                                          C.c_void_p(stream) if stream else None))
 
 
+class ShardedMatcher:
+    """A descriptor database sharded row-wise over several GPUs (mif_match_sharded_*): local top-2 search
+    per shard, one RCCL all-gather of the winners, merge on every rank. Results equal one search over
+    the whole database. All addresses are integer device addresses."""
+
+    def __init__(self, devices, first_rank, nranks, unique_id, max_query, max_shard_rows):
+        self._lib = _lib.load_library()
+        devs = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        idbuf = C.create_string_buffer(bytes(unique_id), _lib.SHARD_ID_BYTES) if unique_id is not None else None
+        _lib.check(self._lib.mif_match_sharded_create(devs, len(devices), first_rank, nranks, idbuf, max_query,
+                                                      max_shard_rows, C.byref(h)))
+        self._h = h
+        self.devices, self.first_rank, self.nranks = list(devices), first_rank, nranks
+
+    @staticmethod
+    def unique_id():
+        """The bytes one rank makes and hands to the others (RCCL's unique id)."""
+        buf = C.create_string_buffer(_lib.SHARD_ID_BYTES)
+        _lib.check(_lib.load_library().mif_match_sharded_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def local(cls, devices, max_query, max_shard_rows):
+        """All ranks in this process, rank i on devices[i]."""
+        return cls(devices, 0, len(devices), None, max_query, max_shard_rows)
+
+    @classmethod
+    def from_process_group(cls, dist, device, max_query, max_shard_rows):
+        """One rank per process of an initialised torch.distributed group: rank 0 makes the id, the group
+        broadcasts it, every rank joins the library's own RCCL communicator."""
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls([device], rank, world, box[0], max_query, max_shard_rows)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mif_match_sharded_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def uses_rccl(self):
+        v = C.c_int()
+        _lib.check(self._lib.mif_match_sharded_ranks(self._h, None, None, C.byref(v)))
+        return bool(v.value)
+
+    def set_screening(self, enable=True):
+        _lib.check(self._lib.mif_match_sharded_set_screening(self._h, 1 if enable else 0))
+
+    def search_all(self, ios, nq, dim, ld):
+        """ios: one dict per local rank with q, shard, rows, offset, idx2, dist2 and optionally stream."""
+        arr = (_lib.ShardIO * len(ios))()
+        for a, io in zip(arr, ios):
+            a.d_q, a.d_shard = io["q"], io["shard"]
+            a.shard_rows, a.global_offset = io["rows"], io["offset"]
+            a.d_idx2, a.d_dist2 = io["idx2"], io["dist2"]
+            a.stream = io.get("stream")
+        _lib.check(self._lib.mif_match_sharded_search(self._h, arr, nq, dim, ld))
+
+    def search(self, d_q, nq, d_shard, rows, offset, dim, ld, d_idx2, d_dist2, stream=None):
+        """The call of a process that holds one rank."""
+        self.search_all([dict(q=d_q, shard=d_shard, rows=rows, offset=offset, idx2=d_idx2, dist2=d_dist2,
+                              stream=stream)], nq, dim, ld)
+
+    def sync(self):
+        _lib.check(self._lib.mif_match_sharded_sync(self._h))
+
+
 def pack_sift_rows(descriptors):
     """Descriptor matrix as fmatches::ConvertToSift_feat + ConvertToCVKeyPoint build it
     (common/kpmatch.h:15,127-128,141-142): sift_feat::descriptor starts with one zero
