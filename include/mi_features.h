@@ -41,6 +41,12 @@ extern "C" {
 
 const char* mif_last_error(void);
 int mif_device_count(void);
+/* Test hook without counterpart in the reference: evaluates on the GPU the elementary functions the
+ * kernels use in place of the reference's native_exp / native_powr / sin / cos / atan2 (OpenCL built-ins
+ * under -cl-fast-relaxed-math, SIFT/sift.cpp:1369-1370), so that a checker compiled for the host from
+ * the same definitions can be compared with them bit for bit. op: 0 exp, 1 exp2, 2 sin, 3 cos,
+ * 4 atan2(a, b), 5 exp without range guards (-87 <= a <= 88). a, b, out: n host floats (b only for op 4). */
+int mif_math_probe(int device, int op, const float* a, const float* b, float* out, int n);
 
 /* ------------------------------------------------------------------ SIFT -- */
 

@@ -19,6 +19,7 @@ _PF = C.POINTER(C.c_float)
 SYMBOLS = [
     ("mif_last_error", C.c_char_p, []),
     ("mif_device_count", C.c_int, []),
+    ("mif_math_probe", C.c_int, [C.c_int, C.c_int, _P, _P, _P, C.c_int]),
     ("mif_sift_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("mif_sift_create_batched", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("mif_sift_batch", C.c_int, [_P]),

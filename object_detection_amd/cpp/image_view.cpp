@@ -106,6 +106,26 @@ namespace mif
         }
     }
 
+    size_t FrameReader::count(size_t limit) const
+    {
+        if (!opened_) return 0;
+        if (raw_) {
+            std::ifstream in(path_, std::ios::binary | std::ios::ate);
+            const size_t bytes = (size_t)w_ * h_ * c_;
+            const size_t n = in.is_open() ? (size_t)in.tellg() / bytes : 0;
+            return n < limit ? n : limit;
+        }
+        size_t n = 0;
+        for (; n < limit; n++) {
+            char name[4096];
+            std::snprintf(name, sizeof(name), path_.c_str(), (int)n);
+            if (n > 0 && std::string(name) == path_) break;                // a single file, not a pattern
+            std::ifstream probe(name, std::ios::binary);
+            if (!probe.is_open()) break;
+        }
+        return n;
+    }
+
     bool FrameReader::read(Image& frame)
     {
         if (!opened_) return false;

@@ -45,6 +45,8 @@ namespace mif
         explicit FrameReader(const std::string& spec);
         bool isOpened() const { return opened_; }
         bool read(Image& frame);                 // false at the end of the sequence
+        void seek(size_t index) { index_ = index; }      // the next read returns frame `index`
+        size_t count(size_t limit) const;        // frames in the sequence, counted up to `limit`
     private:
         bool opened_ = false, raw_ = false;
         std::string path_;

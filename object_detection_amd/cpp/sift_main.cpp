@@ -1,8 +1,9 @@
 // demo_coopcl_sift: the command line of the reference's SIFT demo (SIFT/main.cpp) on the GPU path.
 //   -m object.pgm scene.pgm -f x   extract both, match, homography; report to stdout (+ -o report.json)
-//   -v frames -f x [-b N]          per-frame extraction and matching against the previous frame;
+//   -v frames -f x [-b N] [-g G]   per-frame extraction and matching against the previous frame;
 //                                  frames = "file.raw:WxHxC" or a printf pattern of PGM/PPM files;
-//                                  -b N sends batches of N frames through the GPU-resident pipeline
+//                                  -b N sends batches of N frames through the GPU-resident pipeline;
+//                                  -g G cuts the sequence into G blocks, one GPU and host thread each
 //   -i image -f x                  extract one image, print the feature count
 // -c (camera) needs a capture device and a display and is not available in this headless build.
 #include <algorithm>
@@ -10,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <thread>
+#include <vector>
 
 #include "kpmatch.h"
 #include "../../include/mi_features.h"
@@ -102,43 +105,38 @@ static int call_stream_demo(const std::string& input, float offload)
     return 0;
 }
 
-// The same loop for whole batches of frames (-b N): the frames go through the library's
-// frame-sequence pipeline (mif_video_*), which keeps them on the GPU, overlaps the upload of one
-// batch with the work on the one before and matches every frame against its predecessor there.
-// Prints the per-frame lines of SIFT/main.cpp:129 once the results are in.
-static int call_stream_demo_batched(const std::string& input, int batch)
+// Frames [start, hi) of the sequence through one frame-sequence pipeline (mif_video_*) on `device`, in
+// batches of `batch`: the frames stay on the GPU, the upload of one batch overlaps the work on the one
+// before, and every frame is matched against its predecessor there. One record per frame in `out`.
+static int run_block(const std::string& input, int device, int batch, size_t start, size_t hi,
+                     std::vector<mif_video_frame>& out, std::string& error)
 {
     mif::FrameReader reader(input);
-    if (!reader.isOpened()) {
-        std::cerr << "Error opening video stream or file:\t" << input << std::endl;
-        return -1;
-    }
-    const size_t max_frames = 100;
+    if (!reader.isOpened()) { error = "cannot open " + input; return -1; }
+    reader.seek(start);
     mif_video* pipe = nullptr;
     int rows = 0, cols = 0, channels = 0;
     // a submitted buffer must stay untouched until the call after next has returned: three in rotation
     std::vector<unsigned char> staging[3];
-    std::vector<mif_video_frame> results;
-    size_t cnt_frames = 0, submitted = 0;
+    size_t at = start, submitted = 0;
     bool more = true;
-    const auto t0 = std::chrono::steady_clock::now();
     auto fail = [&](const char* what) {
-        std::cerr << what << ":\t" << mif_last_error() << std::endl;
+        error = std::string(what) + ": " + mif_last_error();
         if (pipe) mif_video_destroy(pipe);
         return -1;
     };
-    while (more && cnt_frames < max_frames) {
+    while (more && at < hi) {
         std::vector<unsigned char>& buf = staging[submitted % 3];
         int n = 0;
-        while (n < batch && cnt_frames < max_frames) {
+        while (n < batch && at < hi) {
             mif::Image frame;
             if (!reader.read(frame)) { more = false; break; }
             if (!pipe) {
                 rows = frame.rows; cols = frame.cols; channels = frame.channels();
-                if (mif_video_create(0, cols, rows, channels, batch, &pipe) != MIF_OK) return fail("pipeline");
+                if (mif_video_create(device, cols, rows, channels, batch, &pipe) != MIF_OK) return fail("pipeline");
             }
             if (frame.rows != rows || frame.cols != cols || frame.channels() != channels) {
-                std::cerr << "Frame " << cnt_frames << " differs in size from the first one" << std::endl;
+                error = "frame " + std::to_string(at) + " differs in size from the first one";
                 more = false;
                 break;
             }
@@ -146,28 +144,79 @@ static int call_stream_demo_batched(const std::string& input, int batch)
             if (buf.size() < bytes * batch) buf.resize(bytes * batch);
             std::copy(frame.data, frame.data + bytes, buf.begin() + bytes * n);
             n++;
-            cnt_frames++;
+            at++;
         }
         if (n == 0) break;
         if (mif_video_submit_host(pipe, buf.data(), n) != MIF_OK) return fail("submit");
         submitted++;
     }
-    if (cnt_frames == 0 || !pipe) return -1;
-    results.resize(cnt_frames);
+    if (at == start || !pipe) { if (error.empty()) error = "no frames"; return -1; }
+    out.resize(at - start);
     int got = 0;
-    if (mif_video_collect(pipe, results.data(), (int)results.size(), &got) != MIF_OK) return fail("collect");
+    if (mif_video_collect(pipe, out.data(), (int)out.size(), &got) != MIF_OK) return fail("collect");
+    out.resize((size_t)got);
+    mif_video_destroy(pipe);
+    return 0;
+}
+
+// The loop of SIFT/main.cpp:103-153 for whole batches of frames (-b N), optionally sharded over GPUs
+// (-g G): the sequence is cut into G contiguous blocks, block g runs on GPU g (modulo the GPUs present)
+// in a host thread of its own with a pipeline of its own, and nothing is exchanged between them. A block
+// that does not start the sequence is extended by the frame before it, so that its first frame is matched
+// against the same predecessor as in a one-GPU run; that extra frame's record is dropped. Prints the
+// per-frame lines of SIFT/main.cpp:129 once the results are in.
+static int call_stream_demo_batched(const std::string& input, int batch, int gpus)
+{
+    mif::FrameReader reader(input);
+    if (!reader.isOpened()) {
+        std::cerr << "Error opening video stream or file:\t" << input << std::endl;
+        return -1;
+    }
+    const size_t max_frames = 100;
+    const size_t total = reader.count(max_frames);
+    if (total == 0) return -1;
+    const int ndev = mif_device_count();
+    if (ndev < 1) { std::cerr << "no GPU" << std::endl; return -1; }
+    const size_t G = (size_t)std::max(1, std::min<int>(gpus, (int)total));
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::vector<mif_video_frame>> part(G);
+    std::vector<std::string> errors(G);
+    std::vector<int> codes(G, 0);
+    std::vector<size_t> first(G + 1, 0);
+    for (size_t g = 0; g < G; g++) first[g + 1] = first[g] + total / G + (g < total % G ? 1 : 0);
+    auto work = [&](size_t g) {
+        const size_t lo = first[g], hi = first[g + 1];
+        const size_t start = lo > 0 ? lo - 1 : lo;
+        codes[g] = run_block(input, (int)(g % (size_t)ndev), batch, start, hi, part[g], errors[g]);
+        if (codes[g] == 0 && start < lo) part[g].erase(part[g].begin());
+    };
+    if (G == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> threads;
+        for (size_t g = 0; g < G; g++) threads.emplace_back(work, g);
+        for (auto& t : threads) t.join();
+    }
+    for (size_t g = 0; g < G; g++) {
+        if (codes[g] != 0) {
+            std::cerr << "block " << g << ":\t" << errors[g] << std::endl;
+            return -1;
+        }
+    }
     const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    size_t total_good = 0;
-    for (int i = 0; i < got; i++) {
-        const mif_video_frame& f = results[i];
-        const int feats = f.status == 0 ? f.keypoints[0] + f.keypoints[1] + f.keypoints[2] : 0;
-        std::cout << "Frame id<" << i << "> Features: <" << feats << ">" << std::endl;
-        if (f.good_matches > 0) total_good += (size_t)f.good_matches;
+    size_t total_good = 0, got = 0;
+    for (size_t g = 0; g < G; g++) {
+        for (const mif_video_frame& f : part[g]) {
+            const int feats = f.status == 0 ? f.keypoints[0] + f.keypoints[1] + f.keypoints[2] : 0;
+            std::cout << "Frame id<" << got << "> Features: <" << feats << ">" << std::endl;
+            if (f.good_matches > 0) total_good += (size_t)f.good_matches;
+            got++;
+        }
     }
     std::cout << "Average time_ms:\t" << wall_ms / got << std::endl;
     std::cout << "Overall time_ms:\t" << wall_ms << std::endl;
-    std::cout << "Frames:\t" << got << "\tgood matches:\t" << total_good << "\twall_ms:\t" << wall_ms << std::endl;
-    mif_video_destroy(pipe);
+    std::cout << "Frames:\t" << got << "\tgood matches:\t" << total_good << "\twall_ms:\t" << wall_ms
+              << "\tGPUs:\t" << std::min<size_t>(G, (size_t)ndev) << "\tblocks:\t" << G << std::endl;
     return 0;
 }
 
@@ -200,7 +249,11 @@ int main(int argc, char** argv)
         return call_single_img_demo(args.img_path_a, args.offload);
     else if (args.app_mode == "-v") {
         const std::string b = option(argc, argv, "-b");
-        if (!b.empty() && std::atoi(b.c_str()) > 0) return call_stream_demo_batched(args.img_path_a, std::atoi(b.c_str()));
+        const std::string g = option(argc, argv, "-g");
+        const int gpus = g.empty() ? 1 : std::atoi(g.c_str());
+        if (gpus > 1 && b.empty()) return call_stream_demo_batched(args.img_path_a, 16, gpus);
+        if (!b.empty() && std::atoi(b.c_str()) > 0)
+            return call_stream_demo_batched(args.img_path_a, std::atoi(b.c_str()), std::max(1, gpus));
         return call_stream_demo(args.img_path_a, args.offload);
     }
     else if (args.app_mode == "-c") {

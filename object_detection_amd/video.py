@@ -48,6 +48,12 @@ class VideoPipeline:
         self._keep = (self._keep + [px])[-3:]          # the upload may still be reading the buffer
         self._waiting += n
 
+    def submit_host_ptr(self, frames_ptr, nframes):
+        """frames_ptr: host address of uint8 [nframes][height][width][channels], e.g. pinned memory (the
+        upload is then asynchronous; the buffer may be rewritten once the call after next has returned)."""
+        _lib.check(self._lib.mif_video_submit_host(self._h, C.c_void_p(frames_ptr), nframes))
+        self._waiting += nframes
+
     def collect(self):
         """Waits for everything submitted; returns a FrameSummary per frame since the last collect."""
         cap = max(self._waiting, 1)

@@ -653,5 +653,21 @@ float orc_math_exp2f(float x) { return mif_exp2f(x); }
 float orc_math_atan2f(float y, float x) { return mif_atan2f(y, x); }
 float orc_math_sinf(float x) { float s, c; mif_sincosf(x, &s, &c); return s; }
 float orc_math_cosf(float x) { float s, c; mif_sincosf(x, &s, &c); return c; }
+// the same functions over arrays; op: 0 exp, 1 exp2, 2 sin, 3 cos, 4 atan2(a, b), 5 exp without range guards
+void orc_math_array(int op, const float* a, const float* b, float* out, int n)
+{
+    for (int i = 0; i < n; i++) {
+        float s, c, r = 0.0f;
+        switch (op) {
+        case 0: r = mif_expf(a[i]); break;
+        case 1: r = mif_exp2f(a[i]); break;
+        case 2: mif_sincosf(a[i], &s, &c); r = s; break;
+        case 3: mif_sincosf(a[i], &s, &c); r = c; break;
+        case 4: r = mif_atan2f(a[i], b[i]); break;
+        case 5: r = mif_expf_bounded(a[i]); break;
+        }
+        out[i] = r;
+    }
+}
 
 } // extern "C"

@@ -37,6 +37,8 @@ def lib():
             getattr(L, name).restype = C.c_float
         L.orc_math_atan2f.argtypes = [C.c_float, C.c_float]
         L.orc_math_atan2f.restype = C.c_float
+        L.orc_math_array.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_math_array.restype = None
         L.orc_match_top2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_match_top2.restype = C.c_int
         L.orc_match_top2_scores.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
@@ -60,6 +62,16 @@ def lib():
         L.orc_get_threads.restype = C.c_int
         _lib = L
     return _lib
+
+
+def math_array(op, a, b=None):
+    """mif_math.h as gcc compiles it, over arrays; op: 0 exp, 1 exp2, 2 sin, 3 cos, 4 atan2(a, b),
+    5 exp without range guards."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(a if b is None else b, np.float32)
+    out = np.empty_like(a)
+    lib().orc_math_array(op, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size)
+    return out
 
 
 def read_pnm(path):

@@ -304,3 +304,36 @@ def test_screening_margin_against_adversarial_rounding():
         assert np.array_equal(i_s[p], i_o), p
         assert np.array_equal(d_s[p].view(np.uint32), d_o.view(np.uint32)), p
         assert np.array_equal(i_o[:, 0], want), p       # the construction holds: X is the true nearest row
+
+
+def test_million_row_database_through_64_screening_splits():
+    """1024 queries against 1 048 576 rows (the row count of the 1 M x 1 M configuration): the database is
+    cut into 64 splits of 16384 rows for the screening passes. Includes rows repeated 40 times inside one
+    split (that split's candidate list overflows and is ranked row by row; ties go to the lowest index),
+    a pair of equal rows in different splits, and an exact copy as nearest row. Checked against the
+    checker, and the plain fp32 search must return the same bits."""
+    import torch
+    dev = torch.device("cuda:0")
+    nd, nq = 1 << 20, 1024
+    base = sift_like_descriptors(65536, seed=7)
+    db = np.concatenate([np.roll(base, r, axis=1) for r in range(nd // 65536)])
+    rng = np.random.RandomState(17)
+    perm = rng.permutation(nd)[:nq]
+    q = np.clip(db[perm] + rng.normal(0, 8, (nq, 128)), 0, 255).astype(np.float32)
+    db[500000:500040] = q[3]                    # 40 copies in one split: the list of that split overflows
+    db[123] = db[900000] = q[5]                 # equal rows in the first and the last but one split
+    db[1048575] = q[7]                          # the very last row
+    idx_o, dist_o = orc.match_top2(q, db)
+    assert list(idx_o[3]) == [500000, 500001] and list(idx_o[5]) == [123, 900000] and idx_o[7, 0] == 1048575
+    tq = torch.from_numpy(q).to(dev)
+    td = torch.from_numpy(db).to(dev)
+    m = oda.Matcher(nq, nd)
+    for screening in (True, False):
+        m.set_screening(screening)
+        idx = torch.full((nq, 2), -9, dtype=torch.int32, device=dev)
+        dist = torch.zeros((nq, 2), dtype=torch.float32, device=dev)
+        m.top2_device(tq.data_ptr(), nq, td.data_ptr(), nd, 128, 128, idx.data_ptr(), dist.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(idx.cpu().numpy(), idx_o), screening
+        assert np.array_equal(dist.cpu().numpy().view(np.uint32), dist_o.view(np.uint32)), screening
+    assert (idx_o[:, 0] == perm).mean() > 0.98

@@ -40,6 +40,87 @@ def test_shared_math_accuracy():
     assert np.abs(c - np.cos(xs.astype(np.float64))).max() <= 3e-7
 
 
+def math_directed_inputs():
+    """Inputs where an elementary function is most likely to go wrong: axes and diagonals of atan2, both
+    signs of zero, the switch points of the argument reductions, denormals, and the ends of the ranges
+    the kernels use. Returns {op: (a, b or None)}."""
+    f32 = np.float32
+    tiny = [f32(1e-45), f32(-1e-45), f32(1.1754942e-38), f32(-1.1754942e-38), f32(1.17549435e-38), f32(1e-30)]
+    mags = [f32(v) for v in (1e-45, 1.1754942e-38, 1e-30, 1e-8, 0.25, 1.0, 3.0, 255.0, 1e8, 3e38)]
+    ys, xs = [], []
+    for m in mags:                                   # axes, diagonals, both signs of zero
+        for sy, sx in ((0.0, 1), (0.0, -1), (-0.0, 1), (-0.0, -1), (1, 0.0), (-1, 0.0), (1, -0.0), (-1, -0.0),
+                       (1, 1), (1, -1), (-1, 1), (-1, -1)):
+            ys.append(f32(sy) * m if sy not in (0.0, -0.0) else f32(sy))
+            xs.append(f32(sx) * m if sx not in (0.0, -0.0) else f32(sx))
+    t8 = f32(0.4142135679721832275390625)            # tan(pi/8): where atan2 changes its reduction
+    for m in (f32(1.0), f32(7.0), f32(1e-20), f32(1e20)):
+        for k in range(-4, 5):
+            r = np.nextafter(t8, f32(2.0 if k > 0 else 0.0)) if k else t8
+            for _ in range(abs(k) - 1):
+                r = np.nextafter(r, f32(2.0 if k > 0 else 0.0))
+            for sy, sx in ((1, 1), (-1, 1), (1, -1), (-1, -1)):
+                ys += [f32(sy) * r * m, f32(sy) * m]
+                xs += [f32(sx) * m, f32(sx) * r * m]
+    ys += [f32(0.0), f32(-0.0), f32(0.0), f32(-0.0)]
+    xs += [f32(0.0), f32(0.0), f32(-0.0), f32(-0.0)]
+    e_in = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, -1e-10, 1e-10, -87.0, -86.999, -87.3365, -88.0, -103.0, -1e30,
+                     88.0, 87.9999, 88.7, 0.34657359, -0.34657359, 0.35, -0.35, 0.6931472, -0.6931472, 1.0, -1.0]
+                    + [0.5 * k * 0.6931471805599453 for k in range(-250, 255)]
+                    + [float(np.nextafter(f32(0.5 * k * 0.6931471805599453), f32(d))) for k in range(-40, 41, 3)
+                       for d in (-1e9, 1e9)], np.float32)
+    e2_in = np.array([0.0, -0.0, 1e-45, 0.5, -0.5, 0.49999997, -0.49999997, 1.5, -1.5, 125.9, -125.9, 1 / 3.0, 2 / 3.0,
+                      1.0, 4 / 3.0] + [k / 3.0 for k in range(-60, 61)] + [k + 0.5 for k in range(-120, 120, 7)],
+                     np.float32)
+    pio4 = 0.7853981633974483
+    sc = [0.0, -0.0, 1e-45, -1e-45, 1e-38, 1e-20, -1e-20, 64.0, -64.0, 63.999996, -63.999996]
+    for k in range(-82, 83):                         # every multiple of pi/4 up to |x| = 64 and its neighbours
+        v = f32(k * pio4)
+        sc += [float(v), float(np.nextafter(v, f32(1e9))), float(np.nextafter(v, f32(-1e9)))]
+    sc = np.array([v for v in sc if abs(v) <= 64.0], np.float32)
+    return {0: (e_in, None), 1: (e2_in, None), 2: (sc, None), 3: (sc, None),
+            4: (np.array(ys, np.float32), np.array(xs, np.float32)),
+            5: (e_in[(e_in >= -87.0) & (e_in <= 88.0)], None)}
+
+
+def test_shared_math_directed_cases():
+    """The elementary functions oracle and kernels share, on the inputs of math_directed_inputs, against
+    libm in double: they are the one piece of arithmetic where the two sides cannot disagree, so their
+    accuracy is pinned here and their GPU build is compared bit for bit in tests/test_sift_gpu.py."""
+    cases = math_directed_inputs()
+    with np.errstate(over="ignore", under="ignore", invalid="ignore"):
+        a, _ = cases[0]
+        got, want = orc.math_array(0, a), np.exp(a.astype(np.float64))
+        fin = (a >= -87.0) & (a <= 88.0)
+        assert _ulp_err(got[fin], want[fin]).max() <= 2.0
+        assert np.all(got[a < -87.0] == 0.0) and np.all(np.isinf(got[a > 88.0]))       # documented range ends
+        assert np.array_equal(orc.math_array(5, a[fin]).view(np.uint32), got[fin].view(np.uint32))
+        a, _ = cases[1]
+        assert _ulp_err(orc.math_array(1, a), np.exp2(a.astype(np.float64))).max() <= 2.0
+        a, _ = cases[2]
+        s, c = orc.math_array(2, a), orc.math_array(3, a)
+        assert np.abs(s - np.sin(a.astype(np.float64))).max() <= 3e-7
+        assert np.abs(c - np.cos(a.astype(np.float64))).max() <= 3e-7
+        small = np.abs(a) < 1e-3                     # relative accuracy where sin x ~ x, denormals included
+        assert np.array_equal(s[small], a[small]) and np.all(c[small] == 1.0)
+        nz = small & (a != 0)                       # sin(-0) comes back as +0 (equal in value)
+        assert np.all(np.signbit(s[nz]) == np.signbit(a[nz]))
+        y, x = cases[4]
+        got = orc.math_array(4, y, x).astype(np.float64)
+        want = np.arctan2(y.astype(np.float64), x.astype(np.float64))
+        both_zero = (y == 0) & (x == 0)
+        assert np.all(got[both_zero] == 0.0)         # stated convention: atan2(+-0, +-0) = 0
+        # y = -0 with x < 0: libm answers -pi, this implementation +pi (the same direction)
+        diff = np.abs(got - want)[~both_zero]
+        diff = np.minimum(diff, np.abs(diff - 2 * math.pi))
+        assert diff.max() <= 5e-7
+        assert np.all(np.abs(got) <= np.float64(np.float32(math.pi)))
+        on_axis = (y == 0) & (x > 0)
+        assert np.all(got[on_axis] == 0.0)
+        up = (x == 0) & (y > 0)
+        assert np.all(got[up] == np.float64(np.float32(math.pi / 2)))
+
+
 def test_taps_match_reference_radii():
     S = orc.SiftOracle(64, 48)
     radii = []

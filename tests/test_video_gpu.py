@@ -139,3 +139,57 @@ def test_two_ranks_shard_a_sequence(tmp_path):
         port = s.getsockname()[1]
     mp.start_processes(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
     assert open(tmp_path / "ok").read() == "1"
+
+
+def test_full_hd_bgr_sequence_against_checker():
+    """Four 1920x1080 BGR frames (the geometry of the headline configuration) through mif_video_* in
+    batches of 3 + 1: status, keypoints per octave, descriptor rows and good matches against the previous
+    frame equal the CPU checker's."""
+    w, h = 1920, 1080
+    frames = [blob_image(w, h, seed=1234, channels=3, shift=(2 * t, t), wrap=True) for t in range(4)]
+    want, prev = [], None
+    S = orc.SiftOracle(w, h, 3)
+    for t, img in enumerate(frames):
+        rc = S.run(img)
+        assert rc == 0
+        counts = [S.count(o) for o in range(3)]
+        des = S.all_features()[3]
+        good = -1
+        if t > 0:
+            _, d = orc.match_top2(oda.pack_sift_rows(des), oda.pack_sift_rows(prev))
+            d0 = d[:, 0].astype(np.float64)
+            good = int((d0 <= max(2.5 * min(100.0, float(d0.min())), 0.35)).sum())
+        want.append((rc, counts, good, len(des)))
+        prev = des
+    vp = oda.VideoPipeline(w, h, 3, batch=3)
+    vp.submit_host(np.stack(frames[0:3]))
+    vp.submit_host(np.stack(frames[3:4]))
+    got = vp.collect()
+    vp.close()
+    assert [(g.status, list(g.keypoints), g.good_matches, g.query_rows) for g in got] == want
+    assert all(w_[2] > 20 for w_ in want[1:]) and all(sum(w_[1]) > 2000 for w_ in want)
+
+
+def test_pinned_host_buffers_reused_as_documented():
+    """mif_video_submit_host with pinned memory copies asynchronously. Three pinned buffers used
+    in rotation and overwritten as soon as the contract allows (once the call after next has returned)
+    must give the records of the same frames submitted from fresh buffers."""
+    import torch
+    n_batches, B = 6, 4
+    frames = [blob_image(W, H, seed=91, n_blobs=140, channels=3, shift=(3 * t, 2 * t)) for t in range(n_batches * B)]
+    vp = oda.VideoPipeline(W, H, 3, batch=B)
+    for k in range(n_batches):
+        vp.submit_host(np.stack(frames[k * B:(k + 1) * B]))
+    want = [tuple(r) for r in vp.collect()]
+    vp.close()
+    vp = oda.VideoPipeline(W, H, 3, batch=B)
+    pinned = [torch.empty((B, H, W, 3), dtype=torch.uint8).pin_memory() for _ in range(3)]
+    for k in range(n_batches):
+        buf = pinned[k % 3]                     # buffer k % 3 was handed over by call k - 3: calls k - 2 and k - 1 have returned
+        buf.copy_(torch.from_numpy(np.stack(frames[k * B:(k + 1) * B])))
+        vp.submit_host_ptr(buf.data_ptr(), B)
+        if k >= 2:
+            pinned[(k - 2) % 3].fill_(0)        # ... so the buffer of call k - 2 may be overwritten now
+    got = [tuple(r) for r in vp.collect()]
+    vp.close()
+    assert got == want and len(got) == n_batches * B
