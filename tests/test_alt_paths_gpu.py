@@ -30,3 +30,13 @@ def test_unfused_paths_equal_the_default(tmp_path):
         a, b = ref[k], alt[k]
         assert a.shape == b.shape, k
         assert a.tobytes() == b.tobytes(), k
+
+
+@pytest.mark.parametrize("mask", ["0", "7"])
+def test_scale_space_levels_singly_or_in_pairs(tmp_path, mask):
+    """MIF_BLUR_PAIRS selects which levels of an octave are built two per launch (default: levels 0 and 1
+    only): one level per launch (0) and all three pairs (7) must give the default's bits."""
+    ref = _run(tmp_path, "default", {})
+    alt = _run(tmp_path, "pairs" + mask, {"MIF_BLUR_PAIRS": mask})
+    for k in ref.files:
+        assert ref[k].shape == alt[k].shape and ref[k].tobytes() == alt[k].tobytes(), k
