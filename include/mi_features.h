@@ -185,6 +185,10 @@ typedef struct mif_ipoint {
  * constructors (ccl_surf.cpp:822-857, 604-663, 181-214) for a width x height
  * image with 1 (gray) or 3 (interleaved BGR) 8-bit channels. */
 int mif_surf_create(int device, int width, int height, int channels, mif_surf** out);
+/* Same, with room for `batch` frames per enqueue: every kernel launch then covers the whole batch
+ * (frames are independent, as successive calls of ccl_surf::run are). mif_surf_create is batch = 1. */
+int mif_surf_create_batched(int device, int width, int height, int channels, int batch, mif_surf** out);
+int mif_surf_batch(const mif_surf* s);
 int mif_surf_destroy(mif_surf* s);
 int mif_surf_capacity(const mif_surf* s);
 
@@ -201,6 +205,12 @@ int mif_surf_run(mif_surf* s, const uint8_t* pixels, mif_ipoint* points, int cap
  * laplacian int32[8000], orientation float[8000], descriptors float[8000][64],
  * counts int32[2] = {points, raw}. Any out pointer may be NULL. */
 int mif_surf_enqueue(mif_surf* s, const void* d_pixels);
+/* nframes (<= batch) frames back to back in HBM; frame f's results start at row f * 8000 of the point
+ * arrays of mif_surf_device_results and at counts + 2 f. */
+int mif_surf_enqueue_batch(mif_surf* s, const void* d_pixels, int nframes);
+/* Waits for the stream and copies the interest points of one frame of the last batch to the host, laid
+ * out as for mif_surf_run. */
+int mif_surf_copy_points(mif_surf* s, int frame, mif_ipoint* points, int capacity, int* count, int* raw_count);
 int mif_surf_sync(mif_surf* s);
 void* mif_surf_stream(mif_surf* s);
 int mif_surf_device_results(mif_surf* s, void** d_pos, void** d_scale, void** d_laplacian, void** d_orientation,
@@ -209,6 +219,7 @@ int mif_surf_device_results(mif_surf* s, void** d_pos, void** d_scale, void** d_
 /* Probes for tests: the integral image (width*height floats) and one response
  * layer (responses / laplacians, either may be NULL) of the last frame. */
 int mif_surf_copy_integral(mif_surf* s, float* out);
+int mif_surf_copy_integral_frame(mif_surf* s, int frame, float* out);
 int mif_surf_layer_info(const mif_surf* s, int layer, int* width, int* height, int* step, int* filter);
 int mif_surf_copy_layer(mif_surf* s, int layer, float* responses, int32_t* laplacians);
 

@@ -46,6 +46,11 @@ SYMBOLS = [
     ("mif_sift_stage_times", C.c_int, [_P, _P]),
     ("mif_sift_last_elapsed_ms", C.c_int, [_P, _PF]),
     ("mif_surf_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("mif_surf_create_batched", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    ("mif_surf_batch", C.c_int, [_P]),
+    ("mif_surf_enqueue_batch", C.c_int, [_P, _P, C.c_int]),
+    ("mif_surf_copy_points", C.c_int, [_P, C.c_int, _P, C.c_int, _PI, _PI]),
+    ("mif_surf_copy_integral_frame", C.c_int, [_P, C.c_int, _P]),
     ("mif_surf_destroy", C.c_int, [_P]),
     ("mif_surf_capacity", C.c_int, [_P]),
     ("mif_surf_run", C.c_int, [_P, _P, _P, C.c_int, _PI, _PI, _PF]),

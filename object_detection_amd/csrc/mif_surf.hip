@@ -71,11 +71,22 @@ __constant__ unsigned char c_orient_item[109];
 // Gray value of one 8-bit pixel as the reference's host code produces it
 // through OpenCV (ccl_surf.cpp:422-449): cvtColor BGR2GRAY fixed point
 // (b*1868 + g*9617 + r*4899 + 8192) >> 14, then convertTo(CV_32F, 1/255).
-__device__ __forceinline__ float gray_of(const uint8_t* __restrict__ px, int i, int channels)
+// `last` is the index of the frame's last pixel: a BGR pixel is fetched as one (unaligned) 32-bit word
+// that starts at its B byte, or one byte earlier for the frame's last pixel so that the word ends with
+// the frame.
+__device__ __forceinline__ float gray_of(const uint8_t* __restrict__ px, int i, int channels, int last)
 {
     int g;
     if (channels == 3) {
-        const int b = px[3 * i], gg = px[3 * i + 1], r = px[3 * i + 2];
+        uint32_t v;
+        if (last >= 1) {
+            const int off = (i < last) ? 3 * i : 3 * i - 1;
+            __builtin_memcpy(&v, px + off, 4);
+            v >>= 8 * (3 * i - off);
+        } else {                                     // a frame of one pixel holds three bytes only
+            v = px[0] | (px[1] << 8) | (px[2] << 16);
+        }
+        const int b = v & 255u, gg = (v >> 8) & 255u, r = (v >> 16) & 255u;
         g = (b * 1868 + gg * 9617 + r * 4899 + (1 << 13)) >> 14;
     } else {
         g = px[i];
@@ -98,31 +109,91 @@ __device__ __forceinline__ float wave_scan64(float v, int lane)
 
 // Row pass (integralImage_kernels.cl:63-152 `scan`, fused with the gray
 // conversion): one wave per image row marches along it 64 pixels at a time.
+// All kernels below take the frame of a batch from a grid dimension and address per-frame data at
+// frame * stride.
 __global__ __launch_bounds__(256) void k_scan_rows(const uint8_t* __restrict__ px, float* __restrict__ out, int w,
                                                    int h, int channels)
 {
+    constexpr int G = 8;                             // 64-pixel chunks whose loads are issued together
     const int lane = threadIdx.x & 63;
     const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (y >= h) return;
+    px += (size_t)blockIdx.y * w * h * channels;
+    out += (size_t)blockIdx.y * w * h;
     float prev = 0.0f;
-    for (int x0 = 0; x0 < w; x0 += 64) {
-        const int x = x0 + lane;
-        float v = (x < w) ? gray_of(px, y * w + x, channels) : 0.0f;
-        v = wave_scan64(v, lane);
-        if (x < w) out[(size_t)y * w + x] = v + prev;
-        prev += __shfl(v, 63);
+    for (int xg = 0; xg < w; xg += 64 * G) {
+        float v[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int x = xg + 64 * g + lane;
+            v[g] = (x < w) ? gray_of(px, y * w + x, channels, w * h - 1) : 0.0f;
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int x = xg + 64 * g + lane;
+            if (xg + 64 * g < w) {                   // uniform over the wave
+                const float sc = wave_scan64(v[g], lane);
+                if (x < w) out[(size_t)y * w + x] = sc + prev;
+                prev += __shfl(sc, 63);
+            }
+        }
     }
 }
 
-// Column pass: the same scan along y (the reference transposes, scans rows and
-// transposes back, ccl_surf.cpp:504-539). A lane owns one column; it loads 64
-// rows, runs the Kogge-Stone tree over them in registers (descending index, so
-// every step reads values of the previous step), adds the running total and
-// stores. Lanes of a wave read consecutive x, so every access is coalesced.
-__global__ __launch_bounds__(64) void k_scan_cols(float* __restrict__ img, int w, int h)
+// Column pass: the same scan along y (the reference transposes, scans rows and transposes back,
+// ccl_surf.cpp:504-539): blocks of 64 rows are scanned with the Kogge-Stone tree and every block adds
+// the running total of the blocks above it, prev_k = (((0 + t_0) + t_1) + ...) + t_(k-1), t = last
+// element of a block's scan (integralImage_kernels.cl:143-150).
+// A workgroup owns a strip of 64 columns of one frame, a wave one block of 64 rows of it (a lane = a
+// column, so every access is a coalesced 256-byte row segment): the wave loads its 64 rows, runs the
+// tree over them in registers (descending index, so every step reads values of the previous step) and
+// publishes its total; after a barrier it sums the totals of the blocks above it in order, adds and
+// stores. The trees of all row blocks of a strip thus run side by side; only the short chain of totals
+// is sequential. Strips taller than 16 blocks take several rounds.
+constexpr int kColWaves = 16;
+constexpr int kColMaxBlocks = 128;      // row blocks per strip the totals table holds (8192 rows)
+
+__global__ __launch_bounds__(64 * kColWaves) void k_scan_cols(float* __restrict__ img, int w, int h)
+{
+    __shared__ float s_tot[kColMaxBlocks * 64];      // [row blocks][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const bool live = x < w;
+    img += (size_t)blockIdx.y * w * h;
+    const int nblocks = (h + 63) / 64;
+    for (int kb0 = 0; kb0 < nblocks; kb0 += kColWaves) {     // uniform over the workgroup
+        const int kb = kb0 + wave;
+        const int y0 = kb * 64;
+        float a[64];
+        if (kb < nblocks) {
+#pragma unroll
+            for (int i = 0; i < 64; i++) a[i] = (live && y0 + i < h) ? img[(size_t)(y0 + i) * w + x] : 0.0f;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+                for (int i = 63; i >= d; i--) a[i] = a[i] + a[i - d];
+            }
+            s_tot[kb * 64 + lane] = a[63];
+        }
+        __syncthreads();
+        if (kb < nblocks) {
+            float prev = 0.0f;
+            for (int j = 0; j < kb; j++) prev += s_tot[j * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 64; i++)
+                if (live && y0 + i < h) img[(size_t)(y0 + i) * w + x] = a[i] + prev;
+        }
+    }
+}
+
+// The same pass with one lane per column walking all row blocks one after the other: for images taller
+// than the tiled kernel's totals table.
+__global__ __launch_bounds__(64) void k_scan_cols_serial(float* __restrict__ img, int w, int h)
 {
     const int x = blockIdx.x * 64 + threadIdx.x;
     if (x >= w) return;
+    img += (size_t)blockIdx.y * w * h;
     float prev = 0.0f;
     for (int y0 = 0; y0 < h; y0 += 64) {
         float a[64];
@@ -171,13 +242,41 @@ __device__ __forceinline__ float haar_y(const float* __restrict__ img, int w, in
            box_integral(img, w, h, row - s / 2, column - s / 2, s / 2, s);
 }
 
+// haar_x and haar_y of one sample together. For even s the four boxes have their corners on a 3 x 3 grid
+// of integral-image positions (rows row - s/2, row, row + s/2; columns likewise), eight of which are
+// used: they are loaded once instead of sixteen times, and every box is then the same expression
+// max(0, A - B - C + D) on the same values as in box_integral.
+__device__ __forceinline__ void haar_xy(const float* __restrict__ img, int w, int h, int row, int column, int s,
+                                        float* hx, float* hy)
+{
+    if (s & 1) {                                     // not reached by the callers (s = 4 k or 2 k)
+        *hx = haar_x(img, w, h, row, column, s);
+        *hy = haar_y(img, w, h, row, column, s);
+        return;
+    }
+    const int half = s / 2;
+    const int r0 = min(row - half, h) - 1, r1 = min(row, h) - 1, r2 = min(row + half, h) - 1;
+    const int c0 = min(column - half, w) - 1, c1 = min(column, w) - 1, c2 = min(column + half, w) - 1;
+    auto at = [&](int r, int c) { return (r >= 0 && c >= 0) ? img[r * w + c] : 0.0f; };
+    const float p00 = at(r0, c0), p01 = at(r0, c1), p02 = at(r0, c2);
+    const float p10 = at(r1, c0), p12 = at(r1, c2);
+    const float p20 = at(r2, c0), p21 = at(r2, c1), p22 = at(r2, c2);
+    *hx = fmaxf(0.0f, p01 - p02 - p21 + p22) - fmaxf(0.0f, p00 - p01 - p20 + p21);
+    *hy = fmaxf(0.0f, p10 - p12 - p20 + p22) - fmaxf(0.0f, p00 - p02 - p10 + p12);
+}
+
 // hessianDet_kernel.cl:105-175 for all eight layers in one launch
 // (grid.z = layer). Work items beyond the layer do not write (the reference's
 // guard only checks the image bounds and writes one element past the row).
 __global__ __launch_bounds__(256) void k_hessian(const float* __restrict__ img, int width, int height, LayerTable tab,
-                                                 float* __restrict__ responses, int* __restrict__ laplacians)
+                                                 float* __restrict__ responses, int* __restrict__ laplacians,
+                                                 size_t pool)
 {
-    const LayerDesc L = tab.l[blockIdx.z];
+    const int frame = blockIdx.z / kLayers;
+    const LayerDesc L = tab.l[blockIdx.z - frame * kLayers];
+    img += (size_t)frame * width * height;
+    responses += (size_t)frame * pool;
+    laplacians += (size_t)frame * pool;
     const int idx = blockIdx.x * 16 + (threadIdx.x & 15);
     const int idy = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (idx >= L.w || idy >= L.h) return;
@@ -310,9 +409,15 @@ __device__ bool interpolate_extremum(const LayerView& t, const LayerView& m, con
 // its count to the row total.
 __global__ __launch_bounds__(64) void k_nms_mark(LayerTable tab, NmsTable nms, const float* __restrict__ responses,
                                                  const int* __restrict__ laps, float threshold,
-                                                 unsigned long long* __restrict__ mask, int* __restrict__ rowcnt)
+                                                 unsigned long long* __restrict__ mask, int* __restrict__ rowcnt,
+                                                 size_t pool)
 {
-    const NmsDesc d = nms.n[blockIdx.z];
+    const int frame = blockIdx.z / kNms;
+    const NmsDesc d = nms.n[blockIdx.z - frame * kNms];
+    responses += (size_t)frame * pool;
+    laps += (size_t)frame * pool;
+    mask += (size_t)frame * nms.rows * nms.words;
+    rowcnt += (size_t)frame * nms.rows;
     const LayerView b = view_of(tab, d.b, responses, laps);
     const LayerView m = view_of(tab, d.m, responses, laps);
     const LayerView t = view_of(tab, d.t, responses, laps);
@@ -331,12 +436,15 @@ __global__ __launch_bounds__(64) void k_nms_mark(LayerTable tab, NmsTable nms, c
     }
 }
 
-// Exclusive scan of the row totals, point count cut at maxIpts. One block.
+// Exclusive scan of the row totals, point count cut at maxIpts. One block per frame.
 __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ rowcnt, int* __restrict__ rowoff,
                                                       int rows, int max_ipts, int* __restrict__ counts)
 {
     __shared__ int s_part[1024];
     const int tid = threadIdx.x;
+    rowcnt += (size_t)blockIdx.x * rows;
+    rowoff += (size_t)blockIdx.x * rows;
+    counts += (size_t)blockIdx.x * 2;
     const int per = (rows + 1023) / 1024;
     const int lo = min(rows, tid * per), hi = min(rows, lo + per);
     int sum = 0;
@@ -367,11 +475,22 @@ __global__ __launch_bounds__(256) void k_nms_emit(LayerTable tab, NmsTable nms, 
                                                   const unsigned long long* __restrict__ mask,
                                                   const int* __restrict__ rowcnt, const int* __restrict__ rowoff,
                                                   int max_ipts, float2* __restrict__ pos, float* __restrict__ scale,
-                                                  int* __restrict__ lap_out)
+                                                  int* __restrict__ lap_out, size_t pool)
 {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nms.rows) return;
+    {
+        const size_t f = blockIdx.y;
+        responses += f * pool;
+        laps += f * pool;
+        mask += f * nms.rows * nms.words;
+        rowcnt += f * nms.rows;
+        rowoff += f * nms.rows;
+        pos += f * max_ipts;
+        scale += f * max_ipts;
+        lap_out += f * max_ipts;
+    }
     if (rowcnt[row] == 0) return;
     int li = 0;
     for (int i = 1; i < kNms; i++)
@@ -435,9 +554,19 @@ __global__ __launch_bounds__(128) void k_orientation(const float* __restrict__ i
 {
     __shared__ float s_rx[109], s_ry[109], s_rz[109];
     __shared__ float s_sx[42], s_sy[42];
-    const int ip = blockIdx.x;
-    if (ip >= counts[0]) return;
+    {
+        const size_t f = blockIdx.y;
+        img += f * w * h;
+        pos += f * kMaxIpts;
+        scale += f * kMaxIpts;
+        orientation += f * kMaxIpts;
+        counts += f * 2;
+    }
     const int tid = threadIdx.x;
+    const int n_ipts = counts[0];
+    // the grid's x extent is smaller than the list capacity: a block walks the frame's points with the
+    // grid's stride (uniform over the block)
+    for (int ip = blockIdx.x; ip < n_ipts; ip += gridDim.x) {
     const int s = (int)mif_roundf(scale[ip]);
     const int r = (int)mif_roundf(pos[ip].y);
     const int c = (int)mif_roundf(pos[ip].x);
@@ -446,8 +575,10 @@ __global__ __launch_bounds__(128) void k_orientation(const float* __restrict__ i
         const int i = localId / 13 - 6;
         const int j = localId % 13 - 6;
         const float gauss = c_gauss25[7 * c_tab_id[i + 6] + c_tab_id[j + 6]];
-        const float rx = gauss * haar_x(img, w, h, r + j * s, c + i * s, 4 * s);
-        const float ry = gauss * haar_y(img, w, h, r + j * s, c + i * s, 4 * s);
+        float hx, hy;
+        haar_xy(img, w, h, r + j * s, c + i * s, 4 * s, &hx, &hy);
+        const float rx = gauss * hx;
+        const float ry = gauss * hy;
         s_rx[tid] = rx;
         s_ry[tid] = ry;
         s_rz[tid] = get_angle(rx, ry);
@@ -488,6 +619,8 @@ __global__ __launch_bounds__(128) void k_orientation(const float* __restrict__ i
         __syncthreads();
     }
     if (tid == 0) orientation[ip] = get_angle(s_sx[0], s_sy[0]);
+    __syncthreads();                                 // the shared arrays are reused by the next point
+    }
 }
 
 // -------------------------------------------------------------- descriptor
@@ -505,9 +638,18 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
 {
     __shared__ float s_d[16][4][81];
     __shared__ float s_len[16];
-    const int ip = blockIdx.x;
-    if (ip >= counts[0]) return;
+    {
+        const size_t f = blockIdx.y;
+        img += f * width * height;
+        pos += f * kMaxIpts;
+        scale += f * kMaxIpts;
+        orientation += f * kMaxIpts;
+        desc += f * kMaxIpts * 64;
+        counts += f * 2;
+    }
     const int tid = threadIdx.x;
+    const int n_ipts = counts[0];
+    for (int ip = blockIdx.x; ip < n_ipts; ip += gridDim.x) {      // uniform over the block
     const float x = mif_roundf(pos[ip].x);
     const float y = mif_roundf(pos[ip].y);
     float si, co;
@@ -528,8 +670,8 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
         const int sample_x = (int)mif_roundf(x + ((float)(-l) * thScale * si + (float)k * thScale * co));
         const int sample_y = (int)mif_roundf(y + ((float)l * thScale * co + (float)k * thScale * si));
         const float gauss_s1 = gaussian(xs - (float)sample_x, ys - (float)sample_y, 2.5f * thScale);
-        const float rx = haar_x(img, width, height, sample_y, sample_x, hs);
-        const float ry = haar_y(img, width, height, sample_y, sample_x, hs);
+        float rx, ry;
+        haar_xy(img, width, height, sample_y, sample_x, hs, &rx, &ry);
         const float rrx = gauss_s1 * (-rx * si + ry * co);
         const float rry = gauss_s1 * (rx * co + ry * si);
         s_d[bIdx][0][tha] = rrx;
@@ -538,13 +680,27 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
         s_d[bIdx][3][tha] = mif_fabsf(rry);
     }
     __syncthreads();
+    // sumDesc (createDescriptors_kernel.cl:133-150) over the 64 arrays of 81 values at once: the step
+    // 81 -> 64 and then strides 32 .. 1, the additions of a step spread over all threads
+    {
+        float* flat = &s_d[0][0][0];
+        for (int item = tid; item < 64 * (81 - 64); item += 256) {
+            const int arr = item / (81 - 64), t = item - arr * (81 - 64);
+            flat[arr * 81 + t] += flat[arr * 81 + t + 64];
+        }
+        __syncthreads();
+        for (int stride = 32; stride > 0; stride >>= 1) {
+            for (int item = tid; item < 64 * stride; item += 256) {
+                const int arr = item / stride, t = item - arr * stride;
+                flat[arr * 81 + t] += flat[arr * 81 + t + stride];
+            }
+            __syncthreads();
+        }
+    }
     float mine = 0.0f;
     if (tid < 64) {
         const int bIdx = tid >> 2, q = tid & 3;
         float* v = s_d[bIdx][q];
-        for (int t = 0; t < 81 - 64; t++) v[t] += v[t + 64];          // sumDesc, first step
-        for (int stride = 32; stride > 0; stride >>= 1)
-            for (int t = 0; t < stride; t++) v[t] += v[t + stride];
         float cx = 0.5f, cy = 0.5f;
         cx += (float)(bIdx / 4);
         cy += (float)(bIdx % 4);
@@ -565,6 +721,8 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
         const float lengthOfDescriptor = 1.0f / __builtin_sqrtf(s_len[0]);
         desc[(size_t)ip * 64 + tid] = mine * lengthOfDescriptor;
     }
+    __syncthreads();                                 // the shared arrays are reused by the next point
+    }
 }
 
 } // namespace
@@ -581,6 +739,13 @@ __global__ void k_pack_points(const float2* __restrict__ pos, const float* __res
 {
     constexpr int kWords = (int)(sizeof(mif_ipoint) / 4);
     static_assert(kWords == 70, "mif_ipoint is 70 words");
+    {
+        const size_t f = blockIdx.y;
+        pos += f * kMaxIpts; scale += f * kMaxIpts; orient += f * kMaxIpts; lap += f * kMaxIpts;
+        desc += f * kMaxIpts * 64;
+        counts += f * 2;
+        out += f * kMaxIpts * kWords;
+    }
     const int total = counts[0] * kWords;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int p = i / kWords, k = i - p * kWords;
@@ -599,7 +764,7 @@ __global__ void k_pack_points(const float2* __restrict__ pos, const float* __res
 } // namespace
 
 struct mif_surf {
-    int device = 0, W = 0, H = 0, C = 1;
+    int device = 0, W = 0, H = 0, C = 1, batch = 1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     LayerTable tab;
@@ -608,7 +773,8 @@ struct mif_surf {
     int nms_max_h = 0;
     uint8_t* d_pixels = nullptr;
     float* integral = nullptr;
-    // responses | laplacians | mask | rowcnt live in ONE allocation that a single memset clears per frame
+    // every buffer holds `batch` frames back to back
+    // responses | laplacians | mask | rowcnt live in ONE allocation that a single memset clears per batch
     void* cleared = nullptr;
     size_t cleared_bytes = 0;
     float* responses = nullptr;
@@ -674,13 +840,14 @@ int surf_create_impl(mif_surf* s)
     s->nms.words = (max_w + 63) / 64;
     s->nms_max_h = max_h;
     const size_t px = (size_t)s->W * s->H;
+    const size_t B = (size_t)s->batch;
     MIF_HIP(hipMalloc(&s->d_pixels, px * s->C));
-    MIF_HIP(hipMalloc(&s->integral, px * sizeof(float)));
+    MIF_HIP(hipMalloc(&s->integral, B * px * sizeof(float)));
     {
         auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        const size_t b_resp = up(s->pool * sizeof(float)), b_lap = up(s->pool * sizeof(int));
-        const size_t b_mask = up((size_t)std::max(rows, 1) * s->nms.words * sizeof(unsigned long long));
-        const size_t b_cnt = up((size_t)std::max(rows, 1) * sizeof(int));
+        const size_t b_resp = up(B * s->pool * sizeof(float)), b_lap = up(B * s->pool * sizeof(int));
+        const size_t b_mask = up(B * (size_t)std::max(rows, 1) * s->nms.words * sizeof(unsigned long long));
+        const size_t b_cnt = up(B * (size_t)std::max(rows, 1) * sizeof(int));
         s->cleared_bytes = b_resp + b_lap + b_mask + b_cnt;
         MIF_HIP(hipMalloc(&s->cleared, s->cleared_bytes));
         char* base = (char*)s->cleared;
@@ -689,16 +856,16 @@ int surf_create_impl(mif_surf* s)
         s->mask = (unsigned long long*)(base + b_resp + b_lap);
         s->rowcnt = (int*)(base + b_resp + b_lap + b_mask);
     }
-    MIF_HIP(hipMalloc(&s->packed, (size_t)kMaxIpts * sizeof(mif_ipoint)));
-    MIF_HIP(hipMalloc(&s->rowoff, (size_t)std::max(rows, 1) * sizeof(int)));
-    MIF_HIP(hipMalloc(&s->counts, 2 * sizeof(int)));
-    MIF_HIP(hipMemset(s->counts, 0, 2 * sizeof(int)));
-    MIF_HIP(hipMalloc(&s->pos, kMaxIpts * sizeof(float2)));
-    MIF_HIP(hipMalloc(&s->scale, kMaxIpts * sizeof(float)));
-    MIF_HIP(hipMalloc(&s->lap, kMaxIpts * sizeof(int)));
-    MIF_HIP(hipMalloc(&s->orient, kMaxIpts * sizeof(float)));
-    MIF_HIP(hipMalloc(&s->desc, (size_t)kMaxIpts * 64 * sizeof(float)));
-    MIF_HIP(hipHostMalloc(&s->h_counts, 2 * sizeof(int)));
+    MIF_HIP(hipMalloc(&s->packed, B * kMaxIpts * sizeof(mif_ipoint)));
+    MIF_HIP(hipMalloc(&s->rowoff, B * (size_t)std::max(rows, 1) * sizeof(int)));
+    MIF_HIP(hipMalloc(&s->counts, B * 2 * sizeof(int)));
+    MIF_HIP(hipMemset(s->counts, 0, B * 2 * sizeof(int)));
+    MIF_HIP(hipMalloc(&s->pos, B * kMaxIpts * sizeof(float2)));
+    MIF_HIP(hipMalloc(&s->scale, B * kMaxIpts * sizeof(float)));
+    MIF_HIP(hipMalloc(&s->lap, B * kMaxIpts * sizeof(int)));
+    MIF_HIP(hipMalloc(&s->orient, B * kMaxIpts * sizeof(float)));
+    MIF_HIP(hipMalloc(&s->desc, B * kMaxIpts * 64 * sizeof(float)));
+    MIF_HIP(hipHostMalloc(&s->h_counts, B * 2 * sizeof(int)));
     unsigned char items[109];
     int k = 0;
     for (int id = 0; id < 169; id++) {
@@ -709,7 +876,9 @@ int surf_create_impl(mif_surf* s)
     return MIF_OK;
 }
 
-int surf_enqueue(mif_surf* s, const void* d_pixels)
+// Enqueues the whole pipeline for `nf` frames (u8 [nf][H][W][C], back to back in device memory): every
+// launch covers all frames of the batch.
+int surf_enqueue(mif_surf* s, const void* d_pixels, int nf)
 {
     hipStream_t st = s->stream;
     const int w = s->W, h = s->H;
@@ -718,27 +887,34 @@ int surf_enqueue(mif_surf* s, const void* d_pixels)
     // positions no work item writes read as zero, as in freshly allocated buffers
     // (one memset: response and laplacian pools, acceptance mask, row counts)
     MIF_HIP(hipMemsetAsync(s->cleared, 0, s->cleared_bytes, st));
-    hipLaunchKernelGGL(k_scan_rows, dim3((h + 3) / 4), dim3(256), 0, st, (const uint8_t*)d_pixels, s->integral, w, h,
+    hipLaunchKernelGGL(k_scan_rows, dim3((h + 3) / 4, nf), dim3(256), 0, st, (const uint8_t*)d_pixels, s->integral, w, h,
                        s->C);
-    hipLaunchKernelGGL(k_scan_cols, dim3((w + 63) / 64), dim3(64), 0, st, s->integral, w, h);
+    if ((h + 63) / 64 <= kColMaxBlocks)
+        hipLaunchKernelGGL(k_scan_cols, dim3((w + 63) / 64, nf), dim3(64 * kColWaves), 0, st, s->integral, w, h);
+    else
+        hipLaunchKernelGGL(k_scan_cols_serial, dim3((w + 63) / 64, nf), dim3(64), 0, st, s->integral, w, h);
     const int lw = std::max(s->tab.l[0].w, 1), lh = std::max(s->tab.l[0].h, 1);
-    hipLaunchKernelGGL(k_hessian, dim3((lw + 15) / 16, (lh + 15) / 16, kLayers), dim3(256), 0, st,
-                       (const float*)s->integral, w, h, s->tab, s->responses, s->laplacians);
-    hipLaunchKernelGGL(k_nms_mark, dim3(s->nms.words, s->nms_max_h, kNms), dim3(64), 0, st, s->tab, s->nms,
-                       (const float*)s->responses, (const int*)s->laplacians, kThres, s->mask, s->rowcnt);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, (const int*)s->rowcnt, s->rowoff, s->nms.rows,
+    hipLaunchKernelGGL(k_hessian, dim3((lw + 15) / 16, (lh + 15) / 16, kLayers * nf), dim3(256), 0, st,
+                       (const float*)s->integral, w, h, s->tab, s->responses, s->laplacians, s->pool);
+    hipLaunchKernelGGL(k_nms_mark, dim3(s->nms.words, s->nms_max_h, kNms * nf), dim3(64), 0, st, s->tab, s->nms,
+                       (const float*)s->responses, (const int*)s->laplacians, kThres, s->mask, s->rowcnt, s->pool);
+    hipLaunchKernelGGL(k_scan_counts, dim3(nf), dim3(1024), 0, st, (const int*)s->rowcnt, s->rowoff, s->nms.rows,
                        kMaxIpts, s->counts);
     if (s->nms.rows > 0)
-        hipLaunchKernelGGL(k_nms_emit, dim3((s->nms.rows + 3) / 4), dim3(256), 0, st, s->tab, s->nms,
+        hipLaunchKernelGGL(k_nms_emit, dim3((s->nms.rows + 3) / 4, nf), dim3(256), 0, st, s->tab, s->nms,
                            (const float*)s->responses, (const int*)s->laplacians,
                            (const unsigned long long*)s->mask, (const int*)s->rowcnt, (const int*)s->rowoff, kMaxIpts,
-                           s->pos, s->scale, s->lap);
-    hipLaunchKernelGGL(k_orientation, dim3(kMaxIpts), dim3(128), 0, st, (const float*)s->integral, w, h,
+                           s->pos, s->scale, s->lap, s->pool);
+    // The point lists hold up to 8000 points per frame and a typical frame a few thousand: the blocks of a
+    // frame walk its list with the grid's stride. One frame gets a block per two list slots, batches get
+    // fewer blocks per frame so that the launch stays at a few thousand blocks.
+    const int per_frame = std::max(64, std::min(kMaxIpts / 2, 16384 / nf));
+    hipLaunchKernelGGL(k_orientation, dim3(per_frame, nf), dim3(128), 0, st, (const float*)s->integral, w, h,
                        (const float2*)s->pos, (const float*)s->scale, (const int*)s->counts, s->orient);
-    hipLaunchKernelGGL(k_descriptor, dim3(kMaxIpts), dim3(256), 0, st, (const float*)s->integral, w, h,
+    hipLaunchKernelGGL(k_descriptor, dim3(per_frame, nf), dim3(256), 0, st, (const float*)s->integral, w, h,
                        (const float2*)s->pos, (const float*)s->scale, (const float*)s->orient, (const int*)s->counts,
                        s->desc);
-    hipLaunchKernelGGL(k_pack_points, dim3(64), dim3(256), 0, st, (const float2*)s->pos, (const float*)s->scale,
+    hipLaunchKernelGGL(k_pack_points, dim3(64, nf), dim3(256), 0, st, (const float2*)s->pos, (const float*)s->scale,
                        (const float*)s->orient, (const int*)s->lap, (const float*)s->desc, (const int*)s->counts,
                        reinterpret_cast<uint32_t*>(s->packed));
     MIF_HIP(hipGetLastError());
@@ -752,17 +928,24 @@ extern "C" {
 
 int mif_surf_create(int device, int width, int height, int channels, mif_surf** out)
 {
+    return mif_surf_create_batched(device, width, height, channels, 1, out);
+}
+
+int mif_surf_batch(const mif_surf* s) { return s ? s->batch : MIF_ERR_INVALID_ARGUMENT; }
+
+int mif_surf_create_batched(int device, int width, int height, int channels, int batch, mif_surf** out)
+{
     if (!out) { mif::set_error("mif_surf_create: out is NULL"); return MIF_ERR_INVALID_ARGUMENT; }
     *out = nullptr;
     if (width <= 0 || height <= 0 || (channels != 1 && channels != 3) ||
-        (long long)width * height * 3 >= (1ll << 31)) {
-        mif::set_error("mif_surf_create: bad geometry %dx%dx%d", width, height, channels);
+        (long long)width * height * 3 >= (1ll << 31) || batch < 1 || batch > 8190) {
+        mif::set_error("mif_surf_create: bad geometry %dx%dx%d, batch %d", width, height, channels, batch);
         return MIF_ERR_INVALID_ARGUMENT;
     }
     mif::DeviceGuard guard(device);
     if (!guard.ok) { mif::set_error("mif_surf_create: cannot select device %d", device); return MIF_ERR_HIP; }
     mif_surf* s = new mif_surf();
-    s->device = device; s->W = width; s->H = height; s->C = channels;
+    s->device = device; s->W = width; s->H = height; s->C = channels; s->batch = batch;
     const int rc = surf_create_impl(s);
     if (rc != MIF_OK) { surf_free(s); delete s; return rc; }
     *out = s;
@@ -785,7 +968,42 @@ int mif_surf_enqueue(mif_surf* s, const void* d_pixels)
 {
     if (!s || !d_pixels) { mif::set_error("mif_surf_enqueue: NULL argument"); return MIF_ERR_INVALID_ARGUMENT; }
     mif::DeviceGuard guard(s->device);
-    return surf_enqueue(s, d_pixels);
+    return surf_enqueue(s, d_pixels, 1);
+}
+
+int mif_surf_enqueue_batch(mif_surf* s, const void* d_pixels, int nframes)
+{
+    if (!s || !d_pixels) { mif::set_error("mif_surf_enqueue_batch: NULL argument"); return MIF_ERR_INVALID_ARGUMENT; }
+    if (nframes < 1 || nframes > s->batch) {
+        mif::set_error("mif_surf_enqueue_batch: %d frames do not fit the handle's batch of %d", nframes, s->batch);
+        return MIF_ERR_CAPACITY;
+    }
+    mif::DeviceGuard guard(s->device);
+    return surf_enqueue(s, d_pixels, nframes);
+}
+
+int mif_surf_copy_points(mif_surf* s, int frame, mif_ipoint* points, int capacity, int* count, int* raw_count)
+{
+    if (!s || !count || (capacity > 0 && !points) || frame < 0 || frame >= s->batch) {
+        mif::set_error("mif_surf_copy_points: bad argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(s->device);
+    *count = 0;
+    MIF_HIP(hipMemcpyAsync(s->h_counts + 2 * frame, s->counts + 2 * frame, 2 * sizeof(int), hipMemcpyDeviceToHost,
+                           s->stream));
+    MIF_HIP(hipStreamSynchronize(s->stream));
+    const int n = s->h_counts[2 * frame];
+    if (raw_count) *raw_count = s->h_counts[2 * frame + 1];
+    if (n > capacity) {
+        mif::set_error("mif_surf_copy_points: %d interest points do not fit capacity %d", n, capacity);
+        return MIF_ERR_CAPACITY;
+    }
+    if (n > 0)
+        MIF_HIP(hipMemcpy(points, s->packed + (size_t)frame * kMaxIpts, (size_t)n * sizeof(mif_ipoint),
+                          hipMemcpyDeviceToHost));
+    *count = n;
+    return MIF_OK;
 }
 
 int mif_surf_sync(mif_surf* s)
@@ -821,7 +1039,7 @@ int mif_surf_run(mif_surf* s, const uint8_t* pixels, mif_ipoint* points, int cap
     mif::DeviceGuard guard(s->device);
     *count = 0;
     MIF_HIP(hipMemcpyAsync(s->d_pixels, pixels, (size_t)s->W * s->H * s->C, hipMemcpyHostToDevice, s->stream));
-    const int rc = surf_enqueue(s, s->d_pixels);
+    const int rc = surf_enqueue(s, s->d_pixels, 1);
     if (rc != MIF_OK) return rc;
     MIF_HIP(hipMemcpyAsync(s->h_counts, s->counts, 2 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
     MIF_HIP(hipStreamSynchronize(s->stream));
@@ -838,12 +1056,15 @@ int mif_surf_run(mif_surf* s, const uint8_t* pixels, mif_ipoint* points, int cap
     return MIF_OK;
 }
 
-int mif_surf_copy_integral(mif_surf* s, float* out)
+int mif_surf_copy_integral(mif_surf* s, float* out) { return mif_surf_copy_integral_frame(s, 0, out); }
+
+int mif_surf_copy_integral_frame(mif_surf* s, int frame, float* out)
 {
-    if (!s || !out) return MIF_ERR_INVALID_ARGUMENT;
+    if (!s || !out || frame < 0 || frame >= s->batch) return MIF_ERR_INVALID_ARGUMENT;
     mif::DeviceGuard guard(s->device);
     MIF_HIP(hipStreamSynchronize(s->stream));
-    MIF_HIP(hipMemcpy(out, s->integral, (size_t)s->W * s->H * sizeof(float), hipMemcpyDeviceToHost));
+    MIF_HIP(hipMemcpy(out, s->integral + (size_t)frame * s->W * s->H, (size_t)s->W * s->H * sizeof(float),
+                      hipMemcpyDeviceToHost));
     return MIF_OK;
 }
 

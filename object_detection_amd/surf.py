@@ -13,12 +13,13 @@ IPOINT_DTYPE = np.dtype([("x", np.float32), ("y", np.float32), ("scale", np.floa
 class SurfExtractor:
     """One GPU SURF pipeline for images of a fixed geometry."""
 
-    def __init__(self, width, height, channels=1, device=0):
+    def __init__(self, width, height, channels=1, device=0, batch=1):
         self._lib = _lib.load_library()
         h = C.c_void_p()
-        _lib.check(self._lib.mif_surf_create(device, width, height, channels, C.byref(h)))
+        _lib.check(self._lib.mif_surf_create_batched(device, width, height, channels, batch, C.byref(h)))
         self._h = h
         self.width, self.height, self.channels, self.device = width, height, channels, device
+        self.batch = batch
         self.capacity = self._lib.mif_surf_capacity(self._h)
 
     def close(self):
@@ -45,6 +46,18 @@ class SurfExtractor:
     def enqueue(self, d_pixels_ptr):
         _lib.check(self._lib.mif_surf_enqueue(self._h, C.c_void_p(d_pixels_ptr)))
 
+    def enqueue_batch(self, d_pixels_ptr, nframes):
+        """d_pixels_ptr: device address of nframes (<= batch) frames of uint8 pixels, back to back."""
+        _lib.check(self._lib.mif_surf_enqueue_batch(self._h, C.c_void_p(d_pixels_ptr), nframes))
+
+    def copy_points(self, frame=0):
+        """Ipoints of one frame of the last batch (structured array) and the raw count."""
+        pts = np.zeros(self.capacity, IPOINT_DTYPE)
+        n, raw = C.c_int(), C.c_int()
+        _lib.check(self._lib.mif_surf_copy_points(self._h, frame, pts.ctypes.data, self.capacity, C.byref(n),
+                                                  C.byref(raw)))
+        return pts[:n.value].copy(), raw.value
+
     def sync(self):
         _lib.check(self._lib.mif_surf_sync(self._h))
 
@@ -56,9 +69,9 @@ class SurfExtractor:
         _lib.check(self._lib.mif_surf_device_results(self._h, *[C.byref(x) for x in v]))
         return tuple(x.value for x in v)      # pos, scale, laplacian, orientation, descriptors, counts
 
-    def integral(self):
+    def integral(self, frame=0):
         out = np.empty((self.height, self.width), np.float32)
-        _lib.check(self._lib.mif_surf_copy_integral(self._h, out.ctypes.data))
+        _lib.check(self._lib.mif_surf_copy_integral_frame(self._h, frame, out.ctypes.data))
         return out
 
     def layer_info(self, i):
