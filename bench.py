@@ -176,17 +176,19 @@ def make_frames(width, height, batch, rank, channels=3):
 
 
 class Pipeline:
-    """Two batched SIFT handles used alternately (own stream each), one matcher on a stream of its own.
+    """Two batched SIFT handles used alternately and one matcher, all on ONE stream.
 
     A step extracts batch k and matches batch k - 1 (every frame against the previous frame; frame 0
     against the last frame of batch k - 2, whose descriptors were copied aside when that batch
     finished). Order on the GPU:
 
-        pyramid(k)  ->  features(k)  ||  matcher(k - 1)   ->  pyramid(k + 1)  -> ...
+        pyramid(k)  ->  matcher(k - 1)  ->  features(k)  ->  pyramid(k + 1)  -> ...
 
-    The scale-space phase (bandwidth kernels) runs alone; the feature phase (vector and latency
-    bound) shares the GPU with the matcher (matrix cores). With serial=True the matcher of batch k
-    runs after features(k) instead and nothing overlaps."""
+    Every kernel of the chain fills the GPU, so a matcher stream of its own (BENCH_MATCH_STREAM=1: the
+    matcher beside the feature phase) gains nothing, and it costs uploads their overlap: a stream that
+    waits for an event blocks the hardware queue it shares with other streams (a process has 4), and
+    the copy stream's commands ended up behind the matcher's wait for pyramid(k). With serial=True the
+    matcher of batch k runs right after features(k)."""
 
     def __init__(self, oda, torch, dev_index, width, height, batch, serial=False, channels=3, match=True):
         from object_detection_amd import _lib
@@ -198,7 +200,11 @@ class Pipeline:
         self.h = [oda.SiftExtractor(width, height, channels, device=dev_index, batch=batch) for _ in range(2)]
         self.cap = self.h[0].capacity
         self.m = oda.Matcher(self.cap, self.cap, device=dev_index, max_pairs=batch)
-        self.mstream = torch.cuda.Stream(device=self.dev)
+        self.h[1].set_stream(self.h[0].stream())
+        if os.environ.get("BENCH_MATCH_STREAM"):
+            self.mstream = torch.cuda.Stream(device=self.dev)
+        else:
+            self.mstream = torch.cuda.ExternalStream(self.h[0].stream(), device=self.dev)
         B, cap = batch, self.cap
         # results of the matcher per handle parity
         self.idx = [torch.zeros((B, cap, 2), dtype=torch.int32, device=self.dev) for _ in range(2)]
@@ -245,11 +251,12 @@ class Pipeline:
     def step(self, frames_ptr):
         k = self.step_no
         h, other, ms = self.h[k % 2], self.h[(k - 1) % 2], self.mstream.cuda_stream
+        # (waits between equal streams return at once: stream order already holds)
         self._wait(h.stream(), other.stream())     # extraction runs batch after batch
         self._wait(h.stream(), ms)                 # the matcher two batches back read this handle's results
         h.enqueue_pyramid(frames_ptr, self.B)
         if self.pending and not self.serial:
-            self._wait(ms, h.stream())             # beside the feature phase, not the scale spaces
+            self._wait(ms, h.stream())             # after the scale spaces
             self._match(k - 1)
         h.enqueue_features(True)
         h.snapshot_frame(self.B - 1, self.snap_des[k % 3].data_ptr(), self.snap_cnt[k % 3].data_ptr())
@@ -457,15 +464,26 @@ def run_native(args, oda, torch, frames, local_rank, world, rank, dist):
     """The timed loop over mif_video_submit_device / mif_video_collect (same schedule, made inside the
     library); prints a reduced line (no roofline: the stage events belong to the handles inside)."""
     vp = oda.VideoPipeline(args.width, args.height, args.channels, batch=args.batch, device=local_rank)
+    if args.host_frames:
+        # three pinned buffers in rotation, as the contract of mif_video_submit_host asks
+        pinned = [frames.cpu().pin_memory() for _ in range(3)]
+        turn = [0]
+
+        def submit():
+            vp.submit_host_ptr(pinned[turn[0] % 3].data_ptr(), args.batch)
+            turn[0] += 1
+    else:
+        def submit():
+            vp.submit_device(frames.data_ptr(), args.batch)
     for _ in range(args.warmup):
-        vp.submit_device(frames.data_ptr(), args.batch)
+        submit()
     vp.collect()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        vp.submit_device(frames.data_ptr(), args.batch)
+        submit()
     res = vp.collect()
     torch.cuda.synchronize()
     if dist is not None:
@@ -480,7 +498,8 @@ def run_native(args, oda, torch, frames, local_rank, world, rank, dist):
                           "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "native pipeline object (mif_video_*), same schedule",
+                          "config": {"workload": "native pipeline object (mif_video_*), same schedule" +
+                                                 (", frames uploaded from pinned host memory" if args.host_frames else ""),
                                      "frames_per_step": args.batch,
                                      "keypoints_last_frame": list(res[-1].keypoints),
                                      "good_matches_last_frame": res[-1].good_matches}}))
@@ -546,21 +565,20 @@ def main():
         """The same step with the batch uploaded from pinned host memory on copy streams (beside the
         previous batch's work) and the match summaries downloaded to pinned host memory."""
         if not host_state:
-            ncopy = max(1, min(int(os.environ.get("BENCH_COPY_STREAMS", "4")), args.batch))
+            ncopy = max(1, min(int(os.environ.get("BENCH_COPY_STREAMS", "1")), args.batch))
             host_state.update(
                 host=torch.from_numpy(frames_np).pin_memory(),
                 dev_buf=[torch.empty_like(frames), frames],
                 cstreams=[torch.cuda.Stream(device=device) for _ in range(ncopy)],
-                dstream=torch.cuda.Stream(device=device),
                 cuts=[args.batch * i // ncopy for i in range(ncopy + 1)],
                 host_summ=[torch.empty((args.batch, 2), dtype=torch.int32).pin_memory() for _ in range(2)])
         hs = host_state
         k = pipe.step_no
         hk = pipe.h[k % 2]
-        # buffer k % 2 was last read by the scale spaces of batch k - 2, enqueued on this handle's stream
-        # (several copy streams: one DMA engine alone does not fill the link)
+        # buffer k % 2 was last read by the first octave's scale space of batch k - 2 on this handle.
+        # One copy stream: a single stream reaches the link's rate (57.6 GB/s measured, tools/micro/h2d_bw.hip)
         for ci, cs in enumerate(hs["cstreams"]):
-            pipe._wait(cs.cuda_stream, hk.stream())
+            hk.wait_input_read(cs.cuda_stream)
             with torch.cuda.stream(cs):
                 hs["dev_buf"][k % 2][hs["cuts"][ci]:hs["cuts"][ci + 1]].copy_(
                     hs["host"][hs["cuts"][ci]:hs["cuts"][ci + 1]], non_blocking=True)
@@ -568,9 +586,8 @@ def main():
             pipe._wait(hk.stream(), cs.cuda_stream)
         pipe.step(hs["dev_buf"][k % 2].data_ptr())
         if k >= 1 and pipe.match and not pipe.serial:
-            # the matcher of batch k - 1 has just been enqueued: its summaries go back to the host
-            pipe._wait(hs["dstream"].cuda_stream, pipe.mstream.cuda_stream)
-            with torch.cuda.stream(hs["dstream"]):
+            # the matcher of batch k - 1 has just been enqueued: its summaries go back to the host behind it
+            with torch.cuda.stream(pipe.mstream):
                 hs["host_summ"][(k - 1) % 2].copy_(pipe.summ[(k - 1) % 2], non_blocking=True)
 
     def timed_region(step, warmup, steps):
@@ -684,7 +701,9 @@ def main():
                                                                        args.channels)),
                        "frames_per_step": args.batch, "octaves": 3, "levels": 6,
                        "pipeline": "matcher after each batch" if args.serial else
-                                   "matcher of batch k-1 beside the feature phase of batch k",
+                                   ("matcher of batch k-1 beside the feature phase of batch k"
+                                    if os.environ.get("BENCH_MATCH_STREAM") else
+                                    "one stream: pyramid(k), matcher(k-1), features(k)"),
                        "keypoints_last_frame": keypoints_last, "good_matches_last_frame": good_last,
                        "parallelism": "frames sharded over %d GPU(s), no collective" % world,
                        "world_size": world_seen,
@@ -718,8 +737,10 @@ def main():
     match_ok = True
     if args.match_rows > 0 and not args.no_match:
         pipe.sync()
-        del pipe, frames, step, timed
+        # the pinned buffers go first: torch's host allocator records an event on every stream that used
+        # them when they are freed, and the handles' stream is gone once the pipeline is
         host_state.clear()
+        del pipe, frames, step, timed
         torch.cuda.empty_cache()
         if world > 1 and backend != "nccl":
             blk = {"skipped": "rehearsal with ranks sharing a GPU: RCCL needs one GPU per rank"}

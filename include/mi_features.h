@@ -126,6 +126,19 @@ int mif_sift_device_results(mif_sift* s, void** d_keypoints, void** d_orientatio
                             void** d_counts);
 /* The handle's hipStream_t, for callers that order their own work after a frame. */
 void* mif_sift_stream(mif_sift* s);
+/* Makes the handle enqueue on a stream of the caller's from now on (NULL: back to its own). Handles
+ * whose work is ordered one after the other anyway -- the two handles a video pipeline alternates
+ * between -- can share one stream: a process has few hardware queues (4 by default) for all its
+ * streams, and streams that share a queue wait behind each other's kernels, e.g. an upload behind a
+ * matcher. Waits for what the handle has enqueued so far. No counterpart in the reference. */
+int mif_sift_set_stream(mif_sift* s, void* stream);
+/* Makes everything enqueued on `waiter` (a hipStream_t) from now on wait until the pixels of the batch
+ * last enqueued on s have been read (they are read while the first octave's scale space is built; the
+ * rest of the batch's work does not touch them): the point from which the caller may overwrite a
+ * device-side frame buffer, e.g. with the upload of the batch after next. No host wait; returns at
+ * once when nothing has been enqueued. The reference copies the caller's pixels synchronously
+ * (update_pixels, SIFT/sift.cpp:1540-1552). */
+int mif_sift_wait_input_read(mif_sift* s, void* waiter);
 /* Waits for the stream and reads frame `frame`'s per-octave counts (clamped to
  * max_features) and raw detector totals. Either array may be NULL. Returns the
  * frame's status (0 or MIF_ERR_NO_KEYPOINTS). */

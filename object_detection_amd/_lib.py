@@ -37,6 +37,8 @@ SYMBOLS = [
     ("mif_sift_sync", C.c_int, [_P]),
     ("mif_sift_device_results", C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     ("mif_sift_stream", _P, [_P]),
+    ("mif_sift_set_stream", C.c_int, [_P, _P]),
+    ("mif_sift_wait_input_read", C.c_int, [_P, _P]),
     ("mif_sift_read_counts", C.c_int, [_P, C.c_int, _PI, _PI]),
     ("mif_sift_copy_level", C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     ("mif_sift_copy_dog", C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),

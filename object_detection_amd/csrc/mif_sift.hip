@@ -1534,8 +1534,11 @@ struct mif_sift {
     int device = 0, W = 0, H = 0, C = 1, cap = 0, batch = 1;
     bool up = false;                       // first octave at twice the input size
     float* zero_row = nullptr;             // widest octave row of zeros: the blur's padding rows
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // where the handle enqueues: its own stream unless mif_sift_set_stream
+    hipStream_t own_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_dep = nullptr;
+    hipEvent_t ev_input = nullptr;         // the last batch's pixels have been read (first octave's scale space built)
+    bool input_pending = false;
     OctaveBuf oct[kOctaves];
     uint8_t* d_pixels = nullptr;           // staging for the host-buffer entry point (one frame)
     float4* kp = nullptr;                  // [batch][cap]
@@ -1758,6 +1761,10 @@ int enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes, bool split =
             }
         }
         if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][2], st));
+        if (o == 0) {                               // nothing after this point reads the caller's pixels
+            MIF_HIP(hipEventRecord(s->ev_input, run));
+            s->input_pending = true;
+        }
     }
     MIF_HIP(hipGetLastError());
     s->pyramid_frames = nf;
@@ -1892,19 +1899,26 @@ void free_all(mif_sift* s)
             if (s->ev_stage[o][i]) (void)hipEventDestroy(s->ev_stage[o][i]);
             if (s->ev_feat[o][i]) (void)hipEventDestroy(s->ev_feat[o][i]);
         }
-    if (s->stream) (void)hipStreamDestroy(s->stream);
+    if (s->ev_input) (void)hipEventDestroy(s->ev_input);
+    if (s->own_stream) (void)hipStreamDestroy(s->own_stream);
 }
 
 int create_impl(mif_sift* s)
 {
     const size_t B = (size_t)s->batch;
-    MIF_HIP(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    MIF_HIP(hipStreamCreateWithFlags(&s->own_stream, hipStreamNonBlocking));
+    s->stream = s->own_stream;
     MIF_HIP(hipEventCreate(&s->ev0));
     MIF_HIP(hipEventCreate(&s->ev1));
     MIF_HIP(hipEventCreateWithFlags(&s->ev_dep, hipEventDisableTiming));
+    MIF_HIP(hipEventCreateWithFlags(&s->ev_input, hipEventDisableTiming));
     MIF_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
     for (int o = 0; o < kOctaves; o++) {
-        if (o > 0) MIF_HIP(hipStreamCreateWithFlags(&s->aux[o], hipStreamNonBlocking));
+        // Side streams for the octaves of small inputs (see small_input): one-frame handles only. A
+        // process has few hardware queues (4 by default) that all its streams share; a batched pipeline
+        // already keeps two handles, a matcher and a copy stream busy, and every further stream would
+        // end up behind another one's kernels.
+        if (o > 0 && s->batch == 1) MIF_HIP(hipStreamCreateWithFlags(&s->aux[o], hipStreamNonBlocking));
         MIF_HIP(hipEventCreateWithFlags(&s->ev_scan[o], hipEventDisableTiming));
         MIF_HIP(hipEventCreateWithFlags(&s->ev_join[o], hipEventDisableTiming));
         MIF_HIP(hipEventCreateWithFlags(&s->ev_l3[o], hipEventDisableTiming));
@@ -2015,7 +2029,9 @@ int mif_sift_destroy(mif_sift* s)
 {
     if (!s) return MIF_OK;
     mif::DeviceGuard guard(s->device);
-    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    // a stream of the caller's (mif_sift_set_stream) may be gone already: wait for the device instead
+    if (s->stream != s->own_stream) (void)hipDeviceSynchronize();
+    else if (s->stream) (void)hipStreamSynchronize(s->stream);
     free_all(s);
     delete s;
     return MIF_OK;
@@ -2095,6 +2111,7 @@ int mif_stream_wait_stream(int device, void* waiter, void* signaller)
         mif::set_error("mif_stream_wait_stream: device %d out of range", device);
         return MIF_ERR_INVALID_ARGUMENT;
     }
+    if (waiter == signaller) return MIF_OK;         // stream order already holds
     mif::DeviceGuard guard(device);
     if (!guard.ok) { mif::set_error("mif_stream_wait_stream: cannot select device %d", device); return MIF_ERR_HIP; }
     Ring& r = rings[device];
@@ -2104,6 +2121,24 @@ int mif_stream_wait_stream(int device, void* waiter, void* signaller)
     hipError_t e = hipEventRecord(ev, (hipStream_t)signaller);
     if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
     if (e != hipSuccess) { mif::set_error("mif_stream_wait_stream: %s", hipGetErrorString(e)); return MIF_ERR_HIP; }
+    return MIF_OK;
+}
+
+int mif_sift_set_stream(mif_sift* s, void* stream)
+{
+    if (!s) { mif::set_error("mif_sift_set_stream: NULL handle"); return MIF_ERR_INVALID_ARGUMENT; }
+    mif::DeviceGuard guard(s->device);
+    MIF_HIP(hipStreamSynchronize(s->stream));       // nothing of this handle is left on the old stream
+    s->stream = stream ? (hipStream_t)stream : s->own_stream;
+    return MIF_OK;
+}
+
+int mif_sift_wait_input_read(mif_sift* s, void* waiter)
+{
+    if (!s) { mif::set_error("mif_sift_wait_input_read: NULL handle"); return MIF_ERR_INVALID_ARGUMENT; }
+    if (!s->input_pending) return MIF_OK;
+    mif::DeviceGuard guard(s->device);
+    MIF_HIP(hipStreamWaitEvent((hipStream_t)waiter, s->ev_input, 0));
     return MIF_OK;
 }
 

@@ -4,14 +4,19 @@
 // frames that stay on the GPU, with every frame matched against its predecessor
 // under the good-match rule of common/kpmatch.h:177-202.
 //
-// Schedule of batch k (two SIFT handles used alternately, one matcher on a
-// stream of its own):
+// Schedule of batch k (two SIFT handles used alternately and the matcher, all on
+// ONE stream; uploads of host frames on a second one):
 //
-//     pyramid(k)  ->  features(k)  ||  matcher(k - 1)   ->  pyramid(k + 1)  -> ...
+//     pyramid(k)  ->  matcher(k - 1)  ->  features(k)  ->  pyramid(k + 1)  -> ...
+//     upload(k + 1) beside all of it, from the moment pyramid(k - 1) has read its frames
 //
-// The scale-space phase (bandwidth kernels) runs alone; the feature phase
-// (vector and latency bound) shares the GPU with the matcher of the previous
-// batch (matrix cores). Frame 0 of a batch is matched against the last frame of
+// Every kernel of the chain fills the GPU, so running the matcher beside the
+// feature phase on a stream of its own gains nothing (measured), and it costs
+// the uploads their overlap: a process has few hardware queues (4 by default)
+// for all its streams, a stream that waits for an event blocks its whole queue,
+// and a matcher stream waiting for pyramid(k) held up the copy stream's
+// commands behind it (1080p BGR, batch 512: 100 ms per step against 63 ms with
+// one compute stream). Frame 0 of a batch is matched against the last frame of
 // the batch before, whose descriptors are copied aside when that batch finishes.
 // Nothing waits on the host until mif_video_collect.
 #include <cstdint>
@@ -26,7 +31,7 @@ constexpr int kCntWords = 8;            // counts row of a frame: n_oct0..2, n_t
 constexpr int kCntTotal = 3, kCntStatus = 7;
 constexpr int kMatchDim = 127, kMatchLd = 128;   // the shifted descriptor row of kpmatch.h:15,127-128
 
-// host copies of one submitted batch, filled by asynchronous copies on the matcher stream
+// host copies of one submitted batch, filled by asynchronous copies on the compute stream
 struct BatchRecord {
     int nframes = 0;
     bool first_has_previous = false;    // frame 0 was matched (a frame preceded it)
@@ -41,7 +46,8 @@ struct mif_video {
     int device = 0, W = 0, H = 0, C = 0, batch = 0, cap = 0;
     mif_sift* sift[2] = {nullptr, nullptr};
     mif_matcher* matcher = nullptr;
-    hipStream_t mstream = nullptr;      // matcher and result downloads
+    hipStream_t xstream = nullptr;      // everything but the uploads: both handles, matcher, result downloads
+                                        // (the first handle's own stream; not owned here)
     hipStream_t cstream = nullptr;      // uploads of host frames
     // matcher outputs per handle parity
     int32_t* idx[2] = {nullptr, nullptr};       // [batch][cap][2]
@@ -86,7 +92,6 @@ void free_all(mif_video* v)
     }
     for (int i = 0; i < 3; i++) { (void)hipFree(v->snap_des[i]); (void)hipFree(v->snap_cnt[i]); }
     if (v->matcher) (void)mif_match_destroy(v->matcher);
-    if (v->mstream) (void)hipStreamDestroy(v->mstream);
     if (v->cstream) (void)hipStreamDestroy(v->cstream);
 }
 
@@ -108,7 +113,7 @@ int get_record(mif_video* v, BatchRecord* out)
     return MIF_OK;
 }
 
-// Matches batch k (already extracted on handle k % 2) on the matcher stream and downloads its
+// Matches batch k (already extracted on handle k % 2) and downloads its
 // counts and summaries into the batch's record (the newest in flight).
 int enqueue_match(mif_video* v, long long k, int nf)
 {
@@ -145,13 +150,13 @@ int enqueue_match(mif_video* v, long long k, int nf)
     if (!rec.matched) v->pairs.clear();          // the flag was taken when the batch was submitted
     if (!v->pairs.empty()) {
         rc = mif_match_top2_batch_device(v->matcher, v->pairs.data(), (int)v->pairs.size(), v->cap, v->cap, kMatchDim,
-                                         kMatchLd, MIF_FILTER_SIFT, v->mstream);
+                                         kMatchLd, MIF_FILTER_SIFT, v->xstream);
         if (rc != MIF_OK) return rc;
     }
     MIF_HIP(hipMemcpyAsync(rec.h_counts, cnt, (size_t)nf * kCntWords * sizeof(int32_t), hipMemcpyDeviceToHost,
-                           v->mstream));
+                           v->xstream));
     MIF_HIP(hipMemcpyAsync(rec.h_summary, v->summ[hp], (size_t)nf * 2 * sizeof(int32_t), hipMemcpyDeviceToHost,
-                           v->mstream));
+                           v->xstream));
     return MIF_OK;
 }
 
@@ -159,18 +164,11 @@ int submit(mif_video* v, const void* d_frames, int nframes)
 {
     const long long k = v->step;
     mif_sift* h = v->sift[k % 2];
-    mif_sift* other = v->sift[(k + 1) % 2];
-    void* hs = mif_sift_stream(h);
-    int rc = mif_stream_wait_stream(v->device, hs, mif_sift_stream(other));   // extraction runs batch after batch
-    if (rc != MIF_OK) return rc;
-    rc = mif_stream_wait_stream(v->device, hs, v->mstream);   // the matcher two batches back read this handle
-    if (rc != MIF_OK) return rc;
-    rc = mif_sift_enqueue_pyramid(h, d_frames, nframes);
+    // stream order does the rest: the batch before this one and the matcher that read this handle's
+    // results two batches back are on the same stream
+    int rc = mif_sift_enqueue_pyramid(h, d_frames, nframes);
     if (rc != MIF_OK) return rc;
     if (v->pending) {
-        // beside the feature phase, not the scale spaces
-        rc = mif_stream_wait_stream(v->device, v->mstream, hs);
-        if (rc != MIF_OK) return rc;
         // (the record of batch k - 1 is the newest in flight: the one of batch k is added below)
         rc = enqueue_match(v, k - 1, v->pending_frames);
         if (rc != MIF_OK) return rc;
@@ -210,12 +208,17 @@ int mif_video_create(int device, int width, int height, int channels, int batch,
         const int rc = mif_sift_create_batched(device, width, height, channels, 0, batch, &v->sift[i]);
         if (rc != MIF_OK) return fail(rc);
     }
+    // one compute stream for both handles and the matcher (see the head of this file)
+    v->xstream = (hipStream_t)mif_sift_stream(v->sift[0]);
+    {
+        const int rc = mif_sift_set_stream(v->sift[1], v->xstream);
+        if (rc != MIF_OK) return fail(rc);
+    }
     v->cap = mif_sift_capacity(v->sift[0]);
     const size_t cap = (size_t)(v->cap > 0 ? v->cap : 1), B = (size_t)batch;
     int rc = mif_match_create_batched(device, (int)cap, (int)cap, batch, &v->matcher);
     if (rc != MIF_OK) return fail(rc);
-    hipError_t e = hipStreamCreateWithFlags(&v->mstream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&v->cstream, hipStreamNonBlocking);
+    hipError_t e = hipStreamCreateWithFlags(&v->cstream, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
         e = hipMalloc(&v->idx[i], B * cap * 2 * sizeof(int32_t));
         if (e == hipSuccess) e = hipMalloc(&v->dist[i], B * cap * 2 * sizeof(float));
@@ -242,7 +245,6 @@ int mif_video_destroy(mif_video* v)
     mif::DeviceGuard guard(v->device);
     for (int i = 0; i < 2; i++)
         if (v->sift[i]) (void)mif_sift_sync(v->sift[i]);
-    if (v->mstream) (void)hipStreamSynchronize(v->mstream);
     if (v->cstream) (void)hipStreamSynchronize(v->cstream);
     free_all(v);
     delete v;
@@ -279,16 +281,14 @@ int mif_video_submit_host(mif_video* v, const uint8_t* frames, int nframes)
         MIF_HIP(hipEventSynchronize(v->upload_ev[slot]));
         v->upload_pending[slot] = false;
     }
-    // the buffer was last read by the scale spaces of two batches ago, enqueued on this handle's
-    // stream; the upload then runs beside the previous batch (asynchronous for pinned memory)
-    void* hs = mif_sift_stream(v->sift[slot]);
-    int rc = mif_stream_wait_stream(v->device, v->cstream, hs);
+    // the buffer was last read two batches ago, while this slot's handle built the first octave's scale
+    // space; the upload then runs beside everything after that (asynchronous for pinned memory)
+    int rc = mif_sift_wait_input_read(v->sift[slot], v->cstream);
     if (rc != MIF_OK) return rc;
     MIF_HIP(hipMemcpyAsync(v->d_frames[slot], frames, frame_bytes * nframes, hipMemcpyHostToDevice, v->cstream));
     MIF_HIP(hipEventRecord(v->upload_ev[slot], v->cstream));
     v->upload_pending[slot] = true;
-    rc = mif_stream_wait_stream(v->device, hs, v->cstream);
-    if (rc != MIF_OK) return rc;
+    MIF_HIP(hipStreamWaitEvent(v->xstream, v->upload_ev[slot], 0));
     return submit(v, v->d_frames[slot], nframes);
 }
 
@@ -299,13 +299,11 @@ int mif_video_collect(mif_video* v, mif_video_frame* out, int capacity, int* n)
     mif::DeviceGuard guard(v->device);
     if (v->pending) {
         const long long k = v->step - 1;
-        int rc = mif_stream_wait_stream(v->device, v->mstream, mif_sift_stream(v->sift[k % 2]));
-        if (rc != MIF_OK) return rc;
-        rc = enqueue_match(v, k, v->pending_frames);
+        int rc = enqueue_match(v, k, v->pending_frames);
         if (rc != MIF_OK) return rc;
         v->pending = false;
     }
-    MIF_HIP(hipStreamSynchronize(v->mstream));
+    MIF_HIP(hipStreamSynchronize(v->xstream));
     MIF_HIP(hipStreamSynchronize(v->cstream));   // every upload is over: all host buffers are free again
     v->upload_pending[0] = v->upload_pending[1] = false;
     int total = 0;

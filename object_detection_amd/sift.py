@@ -110,6 +110,14 @@ class SiftExtractor:
     def stream(self):
         return self._lib.mif_sift_stream(self._h)
 
+    def wait_input_read(self, waiter_stream):
+        """Work enqueued on `waiter_stream` from now on waits until the last batch's pixels have been read."""
+        _lib.check(self._lib.mif_sift_wait_input_read(self._h, C.c_void_p(waiter_stream)))
+
+    def set_stream(self, stream):
+        """Enqueue on the caller's hipStream_t from now on (None: the handle's own stream again)."""
+        _lib.check(self._lib.mif_sift_set_stream(self._h, C.c_void_p(stream) if stream else None))
+
     def device_results(self):
         kp, ori, des, cnt = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         _lib.check(self._lib.mif_sift_device_results(self._h, C.byref(kp), C.byref(ori), C.byref(des), C.byref(cnt)))
