@@ -172,6 +172,11 @@ int mif_sift_taps(const mif_sift* s, int level, float* out, int capacity);
  * returns the last batch's milliseconds per [octave][stage]. */
 int mif_sift_set_timing(mif_sift* s, int enable);
 int mif_sift_stage_times(mif_sift* s, float ms[MIF_SIFT_OCTAVES][MIF_SIFT_STAGES]);
+/* Kernel launches that built the scale spaces of the last batch enqueued on s, over all octaves: 18
+ * when every level has a launch of its own (the reference: one kBlurH + one kBlurV task per level and
+ * octave, SIFT/sift.cpp:1196-1218), fewer when two levels share one. For per-launch averages of the
+ * scale-space stage time. */
+int mif_sift_blur_launches(const mif_sift* s);
 /* GPU time of the last synchronised frame in ms (hipEvent pair). */
 int mif_sift_last_elapsed_ms(mif_sift* s, float* ms);
 

@@ -1556,6 +1556,7 @@ struct mif_sift {
     hipEvent_t ev_stage[kOctaves][3] = {};   // pyramid phase: before base, before blur, after blur
     hipEvent_t ev_feat[kOctaves][3] = {};    // feature phase: before detection, after emission, at the end
     int pyramid_frames = 0;                  // frames whose scale spaces await the feature phase
+    int blur_launches = 0;                   // scale-space launches of the last enqueue_pyramid (all octaves)
     // streams and events for running the octaves' feature kernels side by side (small inputs)
     hipStream_t aux[kOctaves] = {};          // [0] unused: octave 0 stays on `stream`
     hipEvent_t ev_fork = nullptr, ev_scan[kOctaves] = {}, ev_join[kOctaves] = {}, ev_l3[kOctaves] = {};
@@ -1706,6 +1707,7 @@ int enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes, bool split =
     s->timed_frame = false;
     s->pyramid_frames = 0;
     s->pyramid_split = false;
+    s->blur_launches = 0;
     if (split) {
         MIF_HIP(hipEventRecord(s->ev_fork, st));
         for (int o = 1; o < kOctaves; o++) MIF_HIP(hipStreamWaitEvent(s->aux[o], s->ev_fork, 0));
@@ -1748,6 +1750,7 @@ int enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes, bool split =
             if ((l & 1) == 0 && l + 1 < kLevels && (s->pair_mask >> (l / 2) & 1))
                 paired = launch_blur_pair(s->fr[l], s->fr[l + 1], src, src_stride, dst, dst + items, pyr_stride, O.w, O.h,
                                           nf, s->ktaps[l], s->ktaps[l + 1], s->zero_row, run, kind);
+            s->blur_launches++;
             if (paired) {
                 l++;
             } else {
@@ -2366,6 +2369,11 @@ int mif_sift_stage_times(mif_sift* s, float ms[MIF_SIFT_OCTAVES][MIF_SIFT_STAGES
             else MIF_HIP(hipEventElapsedTime(&ms[o][i], s->ev_feat[o][i - 2], s->ev_feat[o][i - 1]));
         }
     return MIF_OK;
+}
+
+int mif_sift_blur_launches(const mif_sift* s)
+{
+    return s ? s->blur_launches : MIF_ERR_INVALID_ARGUMENT;
 }
 
 int mif_sift_last_elapsed_ms(mif_sift* s, float* ms)

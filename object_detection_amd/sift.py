@@ -140,6 +140,13 @@ class SiftExtractor:
         _lib.check(self._lib.mif_sift_stage_times(self._h, buf))
         return np.array(buf[:], dtype=np.float32).reshape(3, 4)
 
+    def blur_launches(self):
+        """Scale-space kernel launches of the last enqueued batch (18 with one launch per level)."""
+        n = self._lib.mif_sift_blur_launches(self._h)
+        if n < 0:
+            _lib.check(n)
+        return n
+
     def last_elapsed_ms(self):
         ms = C.c_float()
         _lib.check(self._lib.mif_sift_last_elapsed_ms(self._h, C.byref(ms)))

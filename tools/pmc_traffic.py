@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Merges a FETCH_SIZE pass and a WRITE_SIZE pass of `rocprofv3 --pmc` over bench.py into per-launch
-memory-side bytes per kernel, and the scale-space (k_blur_level) total per frame.
+memory-side bytes per kernel, and the scale-space (k_blur_level + k_blur_pair) total per frame.
 
 usage: pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv frames_per_batch out.json
 
@@ -36,7 +36,7 @@ def main():
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     frames = int(sys.argv[3])
     out = {"frames_per_batch": frames, "kernels": {}}
-    blur_bytes = blur_launches = 0.0
+    blur_bytes = blur_launches = last_level_launches = 0.0
     for k in sorted(set(fetch) | set(write)):
         fb, fc = fetch.get(k, (0.0, 0))
         wb, wc = write.get(k, (0.0, 0))
@@ -44,14 +44,17 @@ def main():
         out["kernels"][k] = {"launches": calls, "fetch_bytes_per_launch": FETCH_FACTOR * fb / max(fc, 1),
                              "fetch_size_raw_per_launch": fb / max(fc, 1),
                              "write_bytes_per_launch": wb / max(wc, 1)}
-        if k.startswith("k_blur_level"):
+        if k.startswith("k_blur_level") or k.startswith("k_blur_pair"):
             blur_bytes += FETCH_FACTOR * fb / max(fc, 1) * calls + wb / max(wc, 1) * calls
             blur_launches += calls
-    batches = blur_launches / 18.0                       # 18 blur launches per batch (3 octaves x 6 levels)
+            if k.startswith("k_blur_level<11"):          # the last level: one launch per octave and batch
+                last_level_launches = calls
+    batches = last_level_launches / 3.0
     out["blur_bytes_per_frame"] = blur_bytes / batches / frames
-    out["blur_launches_per_batch"] = 18
+    out["blur_launches_per_batch"] = blur_launches / batches
     json.dump(out, open(sys.argv[4], "w"), indent=1)
-    print("blur bytes per frame: %.1f MB over 18 launches" % (out["blur_bytes_per_frame"] / 1e6))
+    print("blur bytes per frame: %.1f MB over %g launches per batch"
+          % (out["blur_bytes_per_frame"] / 1e6, out["blur_launches_per_batch"]))
 
 
 if __name__ == "__main__":
