@@ -1281,12 +1281,58 @@ __global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ k
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
+// One accepted window sample of kDescriptor (sift.cpp:669-699): weights, orientation bin and the
+// update of the lane's private histogram d[9]. (nx, ny) are the sample's coordinates in units of the
+// cell size relative to the cell centre, |nx|, |ny| < 1; g2 is the gradient plane's entry.
+__device__ __forceinline__ void desc_accumulate(float* __restrict__ d, float nx, float ny, float2 g2, float offx,
+                                                float offy, float ang)
+{
+    const float nxn = mif_fabsf(nx), nyn = mif_fabsf(ny);
+    const float mod = mif_fabsf(g2.x);
+    // atan2(-dy, dx) from the stored atan2(dy, dx): sign bit of g2.x is set iff dy != 0
+    float th = (mif_float_to_bits(g2.x) >> 31) ? -g2.y : g2.y;
+    const float dnx = nx + offx, dny = ny + offy;
+    // |dnx|, |dny| < 2.5 here, so the argument lies in (-1.6, 0]
+    const float ww = mif_expf_bounded(-0.125f * (dnx * dnx + dny * dny));
+    // 1.0 - nxn is evaluated in double in the reference (sift.cpp:675-676); the
+    // difference is exact there, so rounding it to float equals the float subtraction
+    const float wwx = 1.0f - nxn;
+    const float wwy = 1.0f - nyn;
+    const float wgt = ww * wwx * wwy * mod;
+    th -= ang;
+    // The reference wraps with two loops in double, `while (th < 0) th += 2 pi` and
+    // `while (th >= 2 pi) th -= 2 pi`. |theta| and |ang| are at most float(pi), so
+    // th lies in [-2 float(pi), 2 float(pi)]: the first loop runs at most twice
+    // (float(pi) > pi) and the second at most once. (double)th >= 2 pi holds exactly
+    // when th >= float(2 pi), the smallest float above 2 pi, so that test needs no
+    // conversion; 64-bit operations are slow on this GPU.
+    if (th < 0.0f) {
+        th = (float)((double)th + K_M_PI2);
+        if (th < 0.0f) th = (float)((double)th + K_M_PI2);
+    }
+    if (th >= 6.2831854820251465f) {
+        th = (float)((double)th - K_M_PI2);
+        if (th >= 6.2831854820251465f) th = (float)((double)th - K_M_PI2);
+    }
+    const float tth = (float)((double)th * K_RPI);
+    // th is in [0, 2 pi) now, tth in [0, 8]: the floor is the truncation, and the bin as a float is the floor
+    const float ffo = __builtin_floorf(tth);
+    const int fo0 = (int)ffo;
+    const float do0 = tth - ffo;
+    const int fo = fo0 & 7;             // fo0 is in 0..8; same as the reference's % 8
+    d[fo] += (1.0f - do0) * wgt;
+    d[fo + 1] += do0 * wgt;
+}
+
 // sift.cpp:585-709 kDescriptor fused with sift.cpp:712-765 kNormalize. One
 // block of 128 threads per keypoint: 16 cells x 8 lanes, lane l of a cell
 // accumulates window pixels l, l+8, ... into a private 9-bin histogram; bin 8
 // folds into bin 0 and the 8 histograms of a cell are summed in lane order.
 // Normalisation sums the 128 squares sequentially, as the reference's
 // one-thread-per-keypoint kernel does.
+// PLAIN: every window goes through the general loop (the form kept for comparison); otherwise waves
+// whose windows are all at least 8 pixels wide take the streamlined loop below.
+template <bool PLAIN>
 __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ kp, const float* __restrict__ orient,
                                                     const float2* __restrict__ grad, size_t grad_stride, int w, int h,
                                                     int o, int cap, const int* __restrict__ counts,
@@ -1342,7 +1388,43 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
     // a window that is empty in both directions has a positive wx*hy in the
     // reference and would index outside the image; it is treated as empty
     const int loops = (wx > 0 && hy > 0) ? wx * hy : 0;
-    if (loops > 0) {
+    // Streamlined walk for waves whose windows are all at least 8 pixels wide (windows cut by the image
+    // border can be narrower): a step of 8 pixels then wraps into the next row at most once, so the
+    // walk is a handful of selects; coordinates run as floats (small integers: the additions are exact),
+    // a lane is inside its window exactly while its row is, and the gathers go through a buffer
+    // descriptor of the level's plane, whose range check makes the look-ahead of lanes that have left
+    // their window harmless (they read 0 and accumulate nothing). The plane must fit a 32-bit offset.
+    if (!PLAIN && __all(wx >= 8 && hy > 0) && (size_t)w * h < ((size_t)1 << 29)) {
+        const uint32_t lvl = __builtin_amdgcn_readfirstlane((uint32_t)((int)((float)(w * h) * f4.w) - w * h));
+        const float2* plane = grad + lvl;
+        const uint64_t pb = (uint64_t)plane;
+        const uint32_t pb_lo = __builtin_amdgcn_readfirstlane((uint32_t)pb);
+        const uint32_t pb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(pb >> 32));
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)pb_hi << 32) | pb_lo), 0,
+                                                            (int)((uint32_t)(w * h) * 8u), 0x00020000);
+        const float fxmax = (float)xmax, fymax = (float)ymax, fwx = (float)wx;
+        float fx = (float)(xmin + lid), fy = (float)ymin;
+        uint32_t boff = (uint32_t)(ymin * w + xmin + lid) * 8u;
+        const uint32_t inc_wrap = (uint32_t)(8 + w - wx) * 8u;
+        v2f gn = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, boff, 0, 0));
+        while (__any(fy <= fymax)) {
+            const float cfx = fx, cfy = fy;
+            const v2f g = gn;
+            fx += 8.0f;
+            const bool wrap = fx > fxmax;
+            fx -= wrap ? fwx : 0.0f;
+            fy += wrap ? 1.0f : 0.0f;
+            boff += wrap ? inc_wrap : 64u;
+            gn = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, boff, 0, 0));
+            const float dx = cfx - ptx;
+            const float dy = cfy - pty;
+            const float nx = crspt * dx + srspt * dy;
+            const float ny = crspt * dy - srspt * dx;
+            // one combined condition (bit-and): a single branch instead of three nested ones
+            if ((int)(cfy <= fymax) & (int)(mif_fabsf(nx) < 1.0f) & (int)(mif_fabsf(ny) < 1.0f))
+                desc_accumulate(d, nx, ny, make_float2(g.x, g.y), offx, offy, ang);
+        }
+    } else if (loops > 0) {
         // window pixel i = (i / wx + ymin, i % wx + xmin), i = lid, lid + 8, ...
         // The gather of the next window pixel is issued before the current one is
         // processed (whether or not it will pass the cell test), so its latency overlaps
@@ -1366,41 +1448,7 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
             float dy = fy - pty;
             const float nx = crspt * dx + srspt * dy;
             const float ny = crspt * dy - srspt * dx;
-            const float nxn = mif_fabsf(nx), nyn = mif_fabsf(ny);
-            if (nxn < 1.0f && nyn < 1.0f) {
-                const float mod = mif_fabsf(g2.x);
-                // atan2(-dy, dx) from the stored atan2(dy, dx): sign bit of g2.x is set iff dy != 0
-                float th = (mif_float_to_bits(g2.x) >> 31) ? -g2.y : g2.y;
-                const float dnx = nx + offx, dny = ny + offy;
-                // |dnx|, |dny| < 2.5 here, so the argument lies in (-1.6, 0]
-                const float ww = mif_expf_bounded(-0.125f * (dnx * dnx + dny * dny));
-                // 1.0 - nxn is evaluated in double in the reference (sift.cpp:675-676); the
-                // difference is exact there, so rounding it to float equals the float subtraction
-                const float wwx = 1.0f - nxn;
-                const float wwy = 1.0f - nyn;
-                const float wgt = ww * wwx * wwy * mod;
-                th -= ang;
-                // The reference wraps with two loops in double, `while (th < 0) th += 2 pi` and
-                // `while (th >= 2 pi) th -= 2 pi`. |theta| and |ang| are at most float(pi), so
-                // th lies in [-2 float(pi), 2 float(pi)]: the first loop runs at most twice
-                // (float(pi) > pi) and the second at most once. (double)th >= 2 pi holds exactly
-                // when th >= float(2 pi), the smallest float above 2 pi, so that test needs no
-                // conversion; 64-bit operations are slow on this GPU.
-                if (th < 0.0f) {
-                    th = (float)((double)th + K_M_PI2);
-                    if (th < 0.0f) th = (float)((double)th + K_M_PI2);
-                }
-                if (th >= 6.2831854820251465f) {
-                    th = (float)((double)th - K_M_PI2);
-                    if (th >= 6.2831854820251465f) th = (float)((double)th - K_M_PI2);
-                }
-                const float tth = (float)((double)th * K_RPI);
-                const int fo0 = (int)__builtin_floorf(tth);
-                const float do0 = tth - (float)fo0;
-                const int fo = fo0 & 7;             // fo0 is in 0..8; same as the reference's % 8
-                d[fo] += (1.0f - do0) * wgt;
-                d[fo + 1] += do0 * wgt;
-            }
+            if (mif_fabsf(nx) < 1.0f && mif_fabsf(ny) < 1.0f) desc_accumulate(d, nx, ny, g2, offx, offy, ang);
         }
     }
     d[0] += d[8];
@@ -1557,6 +1605,7 @@ struct mif_sift {
     hipEvent_t ev_feat[kOctaves][3] = {};    // feature phase: before detection, after emission, at the end
     int pyramid_frames = 0;                  // frames whose scale spaces await the feature phase
     int blur_launches = 0;                   // scale-space launches of the last enqueue_pyramid (all octaves)
+    bool desc_plain = false;                 // every descriptor window through the general loop (k_descriptor<true>)
     // streams and events for running the octaves' feature kernels side by side (small inputs)
     hipStream_t aux[kOctaves] = {};          // [0] unused: octave 0 stays on `stream`
     hipEvent_t ev_fork = nullptr, ev_scan[kOctaves] = {}, ev_join[kOctaves] = {}, ev_l3[kOctaves] = {};
@@ -1845,10 +1894,15 @@ int enqueue_features(mif_sift* s, int want_desc)
                                    (const float4*)s->kp,
                                    (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap, (const int*)s->counts,
                                    s->orient, s->ori_bins);
-                hipLaunchKernelGGL(k_descriptor, dim3(std::min(O.maxf, std::max(kDescBlocks, kDescBlocksTotal / nf)), nf), dim3(128), 0, so,
-                                   (const float4*)s->kp,
-                                   (const float*)s->orient, (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap,
-                                   (const int*)s->counts, s->desc);
+                const dim3 dgrid(std::min(O.maxf, std::max(kDescBlocks, kDescBlocksTotal / nf)), nf);
+                if (s->desc_plain)
+                    hipLaunchKernelGGL(k_descriptor<true>, dgrid, dim3(128), 0, so, (const float4*)s->kp,
+                                       (const float*)s->orient, (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap,
+                                       (const int*)s->counts, s->desc);
+                else
+                    hipLaunchKernelGGL(k_descriptor<false>, dgrid, dim3(128), 0, so, (const float4*)s->kp,
+                                       (const float*)s->orient, (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap,
+                                       (const int*)s->counts, s->desc);
             }
         } else if (tm) {
             MIF_HIP(hipEventRecord(s->ev_feat[o][1], st));
@@ -1966,6 +2020,7 @@ int create_impl(mif_sift* s)
     build_ori_bins(&s->ori_bins);
     // a BGR pixel is fetched as a 32-bit word, which needs rows of at least four bytes
     if (const char* e = getenv("MIF_BLUR_PAIRS")) s->pair_mask = (unsigned)atoi(e) & 7u;      // A/B switch, 0 = one level per launch
+    if (const char* e = getenv("MIF_DESC_PLAIN")) s->desc_plain = atoi(e) != 0;               // A/B switch
     s->fused_base = s->fr[0] == kBaseRadius && s->oct[kOctaves - 1].w >= 2 && getenv("MIF_NO_FUSED_BASE") == nullptr;
     for (int o = 0; o < kOctaves; o++) {
         OctaveBuf& O = s->oct[o];

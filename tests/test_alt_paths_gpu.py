@@ -1,6 +1,7 @@
 """The library's diagnostic switches select the unfused forms of three stages (gradient planes by a
 kernel of their own, base images written by the gray / decimation kernels, matching without the bf16
-screening passes). Every form must return the same bits as the default path."""
+screening passes) and the general window loop of the descriptor kernel for every keypoint. Every form
+must return the same bits as the default path."""
 import os
 import subprocess
 import sys
@@ -24,7 +25,8 @@ def _run(tmp_path, name, env_extra):
 def test_unfused_paths_equal_the_default(tmp_path):
     ref = _run(tmp_path, "default", {})
     assert int(ref["gray_rc0"]) == 0 and len(ref["gray_kp0"]) > 20 and len(ref["bgr_kp1"]) > 20
-    alt = _run(tmp_path, "alt", {"MIF_NO_FUSED_GRAD": "1", "MIF_NO_FUSED_BASE": "1", "MIF_MATCH_NO_SCREEN": "1"})
+    alt = _run(tmp_path, "alt", {"MIF_NO_FUSED_GRAD": "1", "MIF_NO_FUSED_BASE": "1", "MIF_MATCH_NO_SCREEN": "1",
+                                 "MIF_DESC_PLAIN": "1"})
     assert sorted(ref.files) == sorted(alt.files)
     for k in ref.files:
         a, b = ref[k], alt[k]
