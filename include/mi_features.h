@@ -162,6 +162,18 @@ int mif_sift_copy_dog(mif_sift* s, int frame, int octave, int index, float* out)
  * pixels passed to the last extraction call on `s`, which must still be valid when it is a
  * caller-owned device buffer (mif_sift_enqueue*), resp. from the previous octave's scale space. */
 int mif_sift_copy_base(mif_sift* s, int frame, int octave, float* out);
+/* The resampling probes of the reference's debug build. mif_probe_resize_u8 replaces SIFT::test_kResize
+ * (SIFT/sift.h:28-32, SIFT/sift.cpp:2097-2117): nearest-neighbour resampling of an 8-bit image of
+ * 1 or 3 interleaved channels by (ratio_x, ratio_y) (kResize_NN_1ch_8b / kResize_NN_3ch_8b,
+ * sift.cpp:159-206); `out` takes (int)(width * ratio_x) x (int)(height * ratio_y) pixels.
+ * mif_probe_gray_resize replaces SIFT::test_ColorToGray_Resize (sift.h:34-38, sift.cpp:2119-2144):
+ * kColor_interleaved_ch on a BGR image (channels must be 3), then kResize_NN_1ch_32b (sift.cpp:136-157);
+ * `out` takes as many floats. Destination pixels whose source position lies outside the image are 0.
+ * Like the reference's probes they set up and tear down their own device buffers per call. */
+int mif_probe_resize_u8(int device, const uint8_t* pixels, int width, int height, int channels, float ratio_x,
+                        float ratio_y, uint8_t* out);
+int mif_probe_gray_resize(int device, const uint8_t* pixels, int width, int height, int channels, float ratio_x,
+                          float ratio_y, float* out);
 /* Gaussian taps of a level as the blur kernels use them (2*radius+1 floats;
  * Build_separable_filter_cof, SIFT/sift.cpp:819-889). Returns the radius. */
 int mif_sift_taps(const mif_sift* s, int level, float* out, int capacity);
@@ -391,8 +403,9 @@ int mif_match_sharded_sync(mif_match_sharded* h);
  * frame's features kept for comparison) for batches of frames that stay on the GPU: every
  * frame is extracted and matched against its predecessor (descriptor rows as
  * common/kpmatch.h:127-142 builds them, nearest neighbour kept under the good-match rule
- * of kpmatch.h:177-202). Two batched SIFT handles alternate and the matcher of batch k - 1
- * runs beside the feature phase of batch k; nothing waits on the host before
+ * of kpmatch.h:177-202). Two batched SIFT handles alternate; they and the matcher share one
+ * stream (scale spaces of batch k, matcher of batch k - 1, features of batch k), uploads of
+ * host frames run beside it on a second one; nothing waits on the host before
  * mif_video_collect. Frame 0 of a batch is matched against the last frame of the batch
  * before it. */
 typedef struct mif_video mif_video;

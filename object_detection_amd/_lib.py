@@ -47,6 +47,8 @@ SYMBOLS = [
     ("mif_sift_set_timing", C.c_int, [_P, C.c_int]),
     ("mif_sift_stage_times", C.c_int, [_P, _P]),
     ("mif_sift_blur_launches", C.c_int, [_P]),
+    ("mif_probe_resize_u8", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
+    ("mif_probe_gray_resize", C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _P]),
     ("mif_sift_last_elapsed_ms", C.c_int, [_P, _PF]),
     ("mif_surf_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("mif_surf_create_batched", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),

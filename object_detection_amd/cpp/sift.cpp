@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <fstream>
 #include <iostream>
+#include <string>
 
 #include "../../include/mi_features.h"
 
@@ -16,6 +17,9 @@ namespace
         mif_sift* handle = nullptr;
         int width = 0, height = 0, depth = 0, device = 0;
         std::vector<float> kp, ori, desc, probe;
+        // per-stage GPU times of every extraction so far, [call][octave][stage] (the reference keeps one
+        // record per task call, clDriver.h:1172-1247)
+        std::vector<float> history;
         ~Global() { mif_sift_destroy(handle); }
     };
 
@@ -68,6 +72,11 @@ namespace
         rc = mif_sift_extract(G.handle, image, G.kp.data(), descriptors ? G.ori.data() : nullptr,
                               descriptors ? G.desc.data() : nullptr, mif_sift_capacity(G.handle), counts, &ms);
         elapsed_time = (size_t)ms;
+        {
+            float st[MIF_SIFT_OCTAVES][MIF_SIFT_STAGES];
+            if (G.history.size() < (size_t)1 << 22 && mif_sift_stage_times(G.handle, st) == MIF_OK)
+                G.history.insert(G.history.end(), &st[0][0], &st[0][0] + MIF_SIFT_OCTAVES * MIF_SIFT_STAGES);
+        }
         if (rc != MIF_OK) return rc;
         // octave-major order, SIFT/sift.cpp:1889-1911
         size_t row = 0;
@@ -126,6 +135,10 @@ namespace SIFT
                    &orientations, up_scale);
     }
 
+    // SIFT/sift.cpp:915-957, 1674-1703: the reference writes, per task and octave, the files
+    // <path><task><octave><scale>_off.dat / _cpu.dat / _gpu.dat with one line per call (iteration, value).
+    // Here a stage of an octave takes the place of a task (the kernels are fused differently: see the
+    // names below), the offload is always 1 and the CPU time 0; sift_stage_times.csv holds the last call.
     void store_task_exec_times(const std::string& path)
     {
         Global& G = g();
@@ -141,6 +154,23 @@ namespace SIFT
         ofs << "octave,stage,gpu_ms" << std::endl;
         for (int o = 0; o < MIF_SIFT_OCTAVES; o++)
             for (int s = 0; s < MIF_SIFT_STAGES; s++) ofs << o << "," << names[s] << "," << ms[o][s] << std::endl;
+        // base_image: kColor_interleaved_ch / kDown_pyramid / kResize_NN; scale_space: 6 x (kBlurH, kBlurV);
+        // detector: kReset, kDiff, 3 x kDetector; orientation_descriptor: kOrientation, kDescriptor, kNormalize
+        const size_t per_call = (size_t)MIF_SIFT_OCTAVES * MIF_SIFT_STAGES;
+        const size_t calls = G.history.size() / per_call;
+        for (int o = 0; o < MIF_SIFT_OCTAVES; o++)
+            for (int s = 0; s < MIF_SIFT_STAGES; s++) {
+                const std::string stem = path + names[s] + std::to_string(o) + "0";
+                std::ofstream off(stem + "_off.dat"), cpu(stem + "_cpu.dat"), gpu(stem + "_gpu.dat");
+                off << "iteration\toffload\n";
+                cpu << "iteration\tcpu_time\n";
+                gpu << "iteration\tgpu_time\n";
+                for (size_t it = 0; it < calls; it++) {
+                    off << it + 1 << "\t" << 1 << "\n";
+                    cpu << it + 1 << "\t" << 0 << "\n";
+                    gpu << it + 1 << "\t" << G.history[it * per_call + (size_t)o * MIF_SIFT_STAGES + s] << "\n";
+                }
+            }
     }
 
     size_t cnt_octaves() { return MIF_SIFT_OCTAVES; }
@@ -161,6 +191,30 @@ namespace SIFT
     const float* get_gray(float offload, const unsigned char* image, int width, int height, int color_depth, int oid)
     {
         return probe(2, offload, image, width, height, color_depth, oid, 0);
+    }
+
+    std::vector<std::uint8_t> test_kResize(float offload, const unsigned char* image, int width, int height,
+                                           int color_depth, float ratio_x, float ratio_y)
+    {
+        (void)offload;
+        const int wd = (int)((float)width * ratio_x), hd = (int)((float)height * ratio_y);
+        if (!image || wd < 1 || hd < 1 || color_depth < 1) return {};
+        std::vector<std::uint8_t> out((size_t)wd * hd * color_depth);
+        if (mif_probe_resize_u8(g().device, image, width, height, color_depth, ratio_x, ratio_y, out.data()) != MIF_OK)
+            return {};
+        return out;
+    }
+
+    std::vector<float> test_ColorToGray_Resize(float offload, const unsigned char* image, int width, int height,
+                                               int color_depth, float ratio_x, float ratio_y)
+    {
+        (void)offload;
+        const int wd = (int)((float)width * ratio_x), hd = (int)((float)height * ratio_y);
+        if (!image || wd < 1 || hd < 1) return {};
+        std::vector<float> out((size_t)wd * hd);
+        if (mif_probe_gray_resize(g().device, image, width, height, color_depth, ratio_x, ratio_y, out.data()) != MIF_OK)
+            return {};
+        return out;
     }
 
     void set_device(int device)

@@ -47,7 +47,9 @@ namespace SIFT
         bool up_scale = false);
 
     // SIFT/sift.h:71. Writes <path>sift_stage_times.csv with the GPU time per octave and stage of
-    // the last frame (the reference writes one file per OpenCL task).
+    // the last frame, and per stage and octave the reference's three record files
+    // <path><stage><octave>0_off.dat / _cpu.dat / _gpu.dat (SIFT/sift.cpp:915-957) with one line per
+    // extraction since the pipeline was built; a stage stands where the reference has an OpenCL task.
     void store_task_exec_times(const std::string& path);
 
     // Probes of the reference's _DEBUG build (SIFT/sift.h:9-26): number of octaves / scales and
@@ -62,6 +64,14 @@ namespace SIFT
     // Input of octave oid's scale space: the gray image (octave 0) or the decimated previous octave.
     const float* get_gray(float offload, const unsigned char* image, int width, int height, int color_depth,
                           int oid);
+
+    // Resampling probes of the reference's _DEBUG build (SIFT/sift.h:28-38): nearest-neighbour resize of
+    // the 8-bit image, resp. of its gray conversion, by (ratio_x, ratio_y). An empty vector reports an
+    // error (the reference's versions do not report any).
+    std::vector<std::uint8_t> test_kResize(float offload, const unsigned char* image, int width, int height,
+                                           int color_depth, float ratio_x, float ratio_y);
+    std::vector<float> test_ColorToGray_Resize(float offload, const unsigned char* image, int width, int height,
+                                               int color_depth, float ratio_x, float ratio_y);
 
     // GPU used by the calls above (default 0); changing it drops the cached pipeline.
     void set_device(int device);

@@ -175,6 +175,26 @@ __global__ void k_base_upscaled(const uint8_t* __restrict__ in, float* __restric
     out[(size_t)y * w + x] = v;
 }
 
+// sift.cpp:136-208 kResize_NN_1ch_32b / kResize_NN_1ch_8b / kResize_NN_3ch_8b for the probes
+// test_kResize and test_ColorToGray_Resize (sift.cpp:2097-2144): nearest-neighbour resampling by
+// (ratio_x, ratio_y) of an image of C interleaved channels; destination pixels whose source position
+// falls outside the image are 0.
+template <typename T, int C>
+__global__ void k_resize_nn(T* __restrict__ dst, const T* __restrict__ src, int wd, int hd, int ws, int hs,
+                            float ratio_x, float ratio_y)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x > wd - 1 || y > hd - 1) return;
+    const float fy = ((float)y + 0.4995f) / ratio_y;
+    const float fx = ((float)x + 0.4995f) / ratio_x;
+    const int pd = y * wd + x;
+    const int ps = (int)fy * ws + (int)fx;
+    const bool inside = fx < (float)ws && fy < (float)hs;
+#pragma unroll
+    for (int c = 0; c < C; c++) dst[(size_t)pd * C + c] = inside ? src[(size_t)ps * C + c] : (T)0;
+}
+
 // sift.cpp:113-132 kDown_pyramid with wo = 2w, d = 2, ss_img_id = 3
 // (sift.cpp:1187-1191). `src` is the previous octave's whole pyramid; the
 // source offset 3*(2w)*(2h) and row stride 2w are kept as written, which differs
@@ -2380,6 +2400,72 @@ int mif_sift_copy_base(mif_sift* s, int frame, int octave, float* out)
     MIF_HIP(hipMemcpy(out, O.base + (stored ? (size_t)frame * O.items : 0), O.items * sizeof(float),
                       hipMemcpyDeviceToHost));
     return MIF_OK;
+}
+
+// The reference's probes build their own device and tasks per call (sift.cpp:2103-2106, 2125-2129);
+// here a call allocates its buffers, runs on the null stream and frees them.
+static int probe_resize(int device, const uint8_t* pixels, int width, int height, int channels, float ratio_x,
+                        float ratio_y, bool to_gray, void* out)
+{
+    const char* who = to_gray ? "mif_probe_gray_resize" : "mif_probe_resize_u8";
+    if (!pixels || !out || width < 1 || height < 1 || !(ratio_x > 0.0f) || !(ratio_y > 0.0f) ||
+        (to_gray ? channels != 3 : (channels != 1 && channels != 3))) {
+        mif::set_error("%s: bad argument", who);
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    const int wd = (int)((float)width * ratio_x), hd = (int)((float)height * ratio_y);   // sift.cpp:2108-2109
+    if (wd < 1 || hd < 1 || (double)wd * hd * 3 >= 2147483647.0 || (double)width * height * 3 >= 2147483647.0) {
+        mif::set_error("%s: %d x %d -> %d x %d is out of range", who, width, height, wd, hd);
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(device);
+    if (!guard.ok) { mif::set_error("%s: cannot select device %d", who, device); return MIF_ERR_HIP; }
+    const size_t nsrc = (size_t)width * height, ndst = (size_t)wd * hd;
+    uint8_t *d_src = nullptr, *d_dst8 = nullptr;
+    float *d_gray = nullptr, *d_dstf = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_src); (void)hipFree(d_dst8); (void)hipFree(d_gray); (void)hipFree(d_dstf); };
+    hipError_t e = hipMalloc(&d_src, nsrc * channels);
+    if (e == hipSuccess) e = hipMemcpy(d_src, pixels, nsrc * channels, hipMemcpyHostToDevice);
+    const dim3 grid((wd + 255) / 256, hd);
+    if (to_gray) {
+        if (e == hipSuccess) e = hipMalloc(&d_gray, nsrc * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(&d_dstf, ndst * sizeof(float));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_gray_bgr, dim3((unsigned)((nsrc + 255) / 256)), dim3(256), 0, nullptr, d_src, d_gray,
+                               (int)nsrc);
+            hipLaunchKernelGGL((k_resize_nn<float, 1>), grid, dim3(256), 0, nullptr, d_dstf, (const float*)d_gray, wd,
+                               hd, width, height, ratio_x, ratio_y);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(out, d_dstf, ndst * sizeof(float), hipMemcpyDeviceToHost);
+    } else {
+        if (e == hipSuccess) e = hipMalloc(&d_dst8, ndst * channels);
+        if (e == hipSuccess) {
+            if (channels == 3)
+                hipLaunchKernelGGL((k_resize_nn<uint8_t, 3>), grid, dim3(256), 0, nullptr, d_dst8,
+                                   (const uint8_t*)d_src, wd, hd, width, height, ratio_x, ratio_y);
+            else
+                hipLaunchKernelGGL((k_resize_nn<uint8_t, 1>), grid, dim3(256), 0, nullptr, d_dst8,
+                                   (const uint8_t*)d_src, wd, hd, width, height, ratio_x, ratio_y);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(out, d_dst8, ndst * channels, hipMemcpyDeviceToHost);
+    }
+    cleanup();
+    if (e != hipSuccess) { mif::set_error("%s: %s", who, hipGetErrorString(e)); return MIF_ERR_HIP; }
+    return MIF_OK;
+}
+
+int mif_probe_resize_u8(int device, const uint8_t* pixels, int width, int height, int channels, float ratio_x,
+                        float ratio_y, uint8_t* out)
+{
+    return probe_resize(device, pixels, width, height, channels, ratio_x, ratio_y, false, out);
+}
+
+int mif_probe_gray_resize(int device, const uint8_t* pixels, int width, int height, int channels, float ratio_x,
+                          float ratio_y, float* out)
+{
+    return probe_resize(device, pixels, width, height, channels, ratio_x, ratio_y, true, out);
 }
 
 int mif_sift_taps(const mif_sift* s, int level, float* out, int capacity)

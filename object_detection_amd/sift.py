@@ -201,3 +201,33 @@ def extract_features(image, offload=1.0, want_descriptors=True, device=0, up_sca
         ex = SiftExtractor(w, h, c, device=device, up_scale=up_scale)
         _default[device] = ex
     return ex.extract(img, want_descriptors)
+
+
+def test_kResize(image, ratio_x, ratio_y, device=0):
+    """SIFT::test_kResize (SIFT/sift.h:28-32): nearest-neighbour resampling of an (h, w) or (h, w, 3) uint8
+    image by (ratio_x, ratio_y) on the GPU."""
+    image = np.ascontiguousarray(image, np.uint8)
+    h, w = image.shape[:2]
+    c = 1 if image.ndim == 2 else image.shape[2]
+    wd, hd = int(np.float32(w) * np.float32(ratio_x)), int(np.float32(h) * np.float32(ratio_y))
+    out = np.zeros((max(hd, 0), max(wd, 0)) if c == 1 else (max(hd, 0), max(wd, 0), c), np.uint8)
+    _lib.check(_lib.load_library().mif_probe_resize_u8(device, image.ctypes.data, w, h, c, ratio_x, ratio_y,
+                                                       out.ctypes.data))
+    return out
+
+
+def test_ColorToGray_Resize(image, ratio_x, ratio_y, device=0):
+    """SIFT::test_ColorToGray_Resize (SIFT/sift.h:34-38): gray conversion of an (h, w, 3) BGR uint8 image,
+    then nearest-neighbour resampling by (ratio_x, ratio_y), on the GPU."""
+    image = np.ascontiguousarray(image, np.uint8)
+    h, w = image.shape[:2]
+    c = 1 if image.ndim == 2 else image.shape[2]
+    wd, hd = int(np.float32(w) * np.float32(ratio_x)), int(np.float32(h) * np.float32(ratio_y))
+    out = np.zeros((max(hd, 0), max(wd, 0)), np.float32)
+    _lib.check(_lib.load_library().mif_probe_gray_resize(device, image.ctypes.data, w, h, c, ratio_x, ratio_y,
+                                                         out.ctypes.data))
+    return out
+
+
+test_kResize.__test__ = False                 # not test cases of this package's own test suite
+test_ColorToGray_Resize.__test__ = False

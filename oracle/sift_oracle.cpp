@@ -670,4 +670,44 @@ void orc_math_array(int op, const float* a, const float* b, float* out, int n)
     }
 }
 
+
+// SIFT::test_kResize (SIFT/sift.cpp:2097-2117): kResize_NN_1ch_8b / kResize_NN_3ch_8b (sift.cpp:159-206)
+// over the (int)(width * ratio_x) x (int)(height * ratio_y) destination.
+int orc_resize_u8(const uint8_t* src, int width, int height, int channels, float ratio_x, float ratio_y, uint8_t* dst)
+{
+    const int wd = (int)((float)width * ratio_x), hd = (int)((float)height * ratio_y);
+    for (int y = 0; y < hd; y++)
+        for (int x = 0; x < wd; x++) {
+            const float fy = ((float)y + 0.4995f) / ratio_y;
+            const float fx = ((float)x + 0.4995f) / ratio_x;
+            const int pd = y * wd + x;
+            const int ps = (int)fy * width + (int)fx;
+            const bool inside = fx < (float)width && fy < (float)height;
+            for (int c = 0; c < channels; c++) dst[(size_t)pd * channels + c] = inside ? src[(size_t)ps * channels + c] : 0;
+        }
+    return wd * hd;
+}
+
+// SIFT::test_ColorToGray_Resize (SIFT/sift.cpp:2119-2144): kColor_interleaved_ch (sift.cpp:55-72), then
+// kResize_NN_1ch_32b (sift.cpp:136-157).
+int orc_gray_resize(const uint8_t* bgr, int width, int height, float ratio_x, float ratio_y, float* dst)
+{
+    std::vector<float> gray((size_t)width * height);
+    const float cb = (float)0.114, cg = (float)0.587, cr = (float)0.299;
+    const float val_scale = (float)0.0039215686;
+    for (size_t i = 0; i < gray.size(); i++) {
+        const float b = (float)bgr[3 * i], g = (float)bgr[3 * i + 1], r = (float)bgr[3 * i + 2];
+        gray[i] = (b * cb + g * cg + r * cr) * val_scale;
+    }
+    const int wd = (int)((float)width * ratio_x), hd = (int)((float)height * ratio_y);
+    for (int y = 0; y < hd; y++)
+        for (int x = 0; x < wd; x++) {
+            const float fy = ((float)y + 0.4995f) / ratio_y;
+            const float fx = ((float)x + 0.4995f) / ratio_x;
+            const int ps = (int)fy * width + (int)fx;
+            dst[y * wd + x] = (fx < (float)width && fy < (float)height) ? gray[ps] : 0.0f;
+        }
+    return wd * hd;
+}
+
 } // extern "C"

@@ -44,6 +44,10 @@ def lib():
         L.orc_match_top2_scores.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
         L.orc_match_top2_scores.restype = C.c_int
+        L.orc_resize_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.orc_resize_u8.restype = C.c_int
+        L.orc_gray_resize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+        L.orc_gray_resize.restype = C.c_int
         L.orc_surf_create.restype = C.c_void_p
         L.orc_surf_create.argtypes = [C.c_int, C.c_int]
         L.orc_surf_destroy.argtypes = [C.c_void_p]
@@ -245,3 +249,29 @@ class SurfOracle:
         if n:
             self.L.orc_surf_points(self.h, out.ctypes.data)
         return out
+
+
+def resized_size(width, height, ratio_x, ratio_y):
+    """(int)(width * ratio_x), (int)(height * ratio_y) in float arithmetic (SIFT/sift.cpp:2108-2109)."""
+    return int(np.float32(width) * np.float32(ratio_x)), int(np.float32(height) * np.float32(ratio_y))
+
+
+def resize_u8(img, ratio_x, ratio_y):
+    """SIFT::test_kResize of the reference on an (h, w) or (h, w, 3) uint8 image."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    c = 1 if img.ndim == 2 else img.shape[2]
+    wd, hd = resized_size(w, h, ratio_x, ratio_y)
+    out = np.zeros((hd, wd) if c == 1 else (hd, wd, c), np.uint8)
+    lib().orc_resize_u8(img.ctypes.data, w, h, c, ratio_x, ratio_y, out.ctypes.data)
+    return out
+
+
+def gray_resize(img, ratio_x, ratio_y):
+    """SIFT::test_ColorToGray_Resize of the reference on an (h, w, 3) BGR uint8 image."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    wd, hd = resized_size(w, h, ratio_x, ratio_y)
+    out = np.zeros((hd, wd), np.float32)
+    lib().orc_gray_resize(img.ctypes.data, w, h, ratio_x, ratio_y, out.ctypes.data)
+    return out

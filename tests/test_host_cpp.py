@@ -107,6 +107,15 @@ def test_stream_demo_on_raw_frames(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert "Average time_ms:" in out.stdout and "Frames:\t4" in out.stdout
     assert os.path.exists(tmp_path / "sift_stage_times.csv")
+    # the reference's record files (SIFT/sift.cpp:915-957), one line per extracted frame
+    for stage in ("base_image", "scale_space", "detector", "orientation_descriptor"):
+        for o in range(3):
+            for kind, head in (("off", "offload"), ("cpu", "cpu_time"), ("gpu", "gpu_time")):
+                lines = (tmp_path / ("%s%d0_%s.dat" % (stage, o, kind))).read_text().splitlines()
+                assert lines[0] == "iteration\t" + head and len(lines) == 1 + 4, (stage, o, kind, lines)
+                assert [ln.split("\t")[0] for ln in lines[1:]] == ["1", "2", "3", "4"]
+    gpu_ms = [float(ln.split("\t")[1]) for ln in (tmp_path / "scale_space00_gpu.dat").read_text().splitlines()[1:]]
+    assert all(0.0 < v < 1000.0 for v in gpu_ms)
     out = subprocess.run([_need("demo_coopcl_Surf"), "-v", "%s:320x240x3" % raw, "-f", "0.3"],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "Average elapsed_time:" in out.stdout

@@ -339,3 +339,28 @@ def test_detector_against_second_restatement():
             assert np.array_equal(kp.view(np.uint32), got.view(np.uint32)), o
             total += len(kp)
     assert total > 200
+
+
+@pytest.mark.parametrize("ratio", [(2.0, 2.0), (0.5, 0.5), (1.7, 0.6), (3.0, 1.0)])
+def test_resize_probes_against_numpy(ratio):
+    """The checker's test_kResize / test_ColorToGray_Resize (SIFT/sift.cpp:2097-2144) against a numpy
+    statement of kResize_NN_* (sift.cpp:136-206): source pixel = (trunc((y + 0.4995) / ry), trunc((x + 0.4995) / rx)),
+    0 where that lies outside the image."""
+    rx, ry = ratio
+    rng = np.random.RandomState(5)
+    img = rng.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    h, w = img.shape[:2]
+    wd, hd = orc.resized_size(w, h, rx, ry)
+    f = np.float32
+    fy = (np.arange(hd, dtype=np.float32) + f(0.4995)) / f(ry)
+    fx = (np.arange(wd, dtype=np.float32) + f(0.4995)) / f(rx)
+    sy, sx = fy.astype(np.int32), fx.astype(np.int32)
+    inside = (fy < h)[:, None] & (fx < w)[None, :]
+    src = img[np.minimum(sy, h - 1)[:, None], np.minimum(sx, w - 1)[None, :]]
+    want = np.where(inside[..., None], src, 0).astype(np.uint8)
+    assert np.array_equal(orc.resize_u8(img, rx, ry), want)
+    assert np.array_equal(orc.resize_u8(img[..., 0].copy(), rx, ry), want[..., 0])
+    g = img.astype(np.float32)
+    gray = ((g[..., 0] * f(0.114) + g[..., 1] * f(0.587)) + g[..., 2] * f(0.299)) * f(0.0039215686)
+    wantg = np.where(inside, gray[np.minimum(sy, h - 1)[:, None], np.minimum(sx, w - 1)[None, :]], f(0))
+    assert np.array_equal(orc.gray_resize(img, rx, ry).view(np.uint32), wantg.astype(np.float32).view(np.uint32))

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import object_detection_amd as oda
+from object_detection_amd import _lib
 import oracle_lib as orc
 from make_golden import CASES, load_case
 from synth import blob_image, dense_image
@@ -190,6 +191,26 @@ def test_base_image_probe():
     up = oda.SiftExtractor(200, 150, 3, up_scale=True)
     up.extract(bgr.astype(np.uint8), want_descriptors=False)
     assert np.array_equal(up.base(0), np.repeat(np.repeat(want, 2, axis=0), 2, axis=1))
+
+
+@pytest.mark.parametrize("ratio", [(2.0, 2.0), (0.5, 0.5), (1.7, 0.6), (1.0, 3.0)])
+def test_resize_probes_against_checker(ratio):
+    """SIFT::test_kResize and SIFT::test_ColorToGray_Resize (the resampling probes of the reference's debug
+    build, SIFT/sift.h:28-38) on the GPU against the checker, byte for byte / bit for bit."""
+    from object_detection_amd import sift as sift_mod
+    rx, ry = ratio
+    bgr = load_case("blob_bgr_200x150")
+    out = sift_mod.test_kResize(bgr, rx, ry)
+    assert out.shape[:2] == orc.resized_size(200, 150, rx, ry)[::-1]
+    assert np.array_equal(out, orc.resize_u8(bgr, rx, ry))
+    gray = np.ascontiguousarray(bgr[..., 1])
+    assert np.array_equal(sift_mod.test_kResize(gray, rx, ry), orc.resize_u8(gray, rx, ry))
+    g = sift_mod.test_ColorToGray_Resize(bgr, rx, ry)
+    assert np.array_equal(g.view(np.uint32), orc.gray_resize(bgr, rx, ry).view(np.uint32))
+    with pytest.raises(_lib.MifError):
+        sift_mod.test_ColorToGray_Resize(gray, rx, ry)          # the gray conversion wants BGR
+    with pytest.raises(_lib.MifError):
+        sift_mod.test_kResize(bgr, 0.0, 1.0)
 
 
 def test_shared_math_gpu_build_equals_host_build():

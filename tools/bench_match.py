@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--dim", type=int, default=128)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cpu-queries", type=int, default=0,
+                    help="also time the CPU checker (oracle/, OpenMP) on the first N queries against the whole "
+                         "database and compare its rows with the GPU's (single rank only)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -63,7 +66,8 @@ def main():
     rows = hi - lo
     tq = torch.from_numpy(np.ascontiguousarray(q)).to(dev)
     td = torch.from_numpy(np.ascontiguousarray(db[lo:hi])).to(dev)
-    del db
+    if not (args.cpu_queries > 0 and world == 1):
+        del db
     m = oda.Matcher(args.nq, max(rows, 1), device=local_rank)
     idx = torch.zeros((args.nq, 2), dtype=torch.int32, device=dev)
     dst = torch.zeros((args.nq, 2), dtype=torch.float32, device=dev)
@@ -105,6 +109,19 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_queries > 0:
+        import oracle_lib as orc
+        n = min(args.cpu_queries, args.nq)
+        qc = np.ascontiguousarray(q[:n])
+        tc = time.perf_counter()
+        ci, cd = orc.match_top2(qc, db)
+        dtc = time.perf_counter() - tc
+        same = bool(np.array_equal(ci, wi[:n].cpu().numpy()) and
+                    np.array_equal(cd.view(np.uint32), wd[:n].cpu().numpy().view(np.uint32)))
+        cpu = {"value": n / dtc, "unit": "matches/s", "cores": orc.lib().orc_get_threads(), "kind": "port",
+               "sample": "%d queries x %d rows x %d (OpenMP restatement in oracle/)" % (n, args.nd, args.dim),
+               "equals_gpu_rows_and_distances": same}
     if rank == 0:
         hit = float((wi[:, 0].cpu().numpy() == perm).mean()) if args.nq <= args.nd else None
         flops = 2.0 * args.dim * args.nq * args.nd
@@ -124,7 +141,7 @@ def main():
                                                       if screened else "fp32 matrix instructions"),
                                        "bf16_passes_frac_of_bf16_peak":
                                            (2.0 * flops / dt / 1e12 / (2500.0 * world)) if screened else None},
-                          "true_neighbour_recovered": hit}), flush=True)
+                          "true_neighbour_recovered": hit, "cpu_baseline": cpu}), flush=True)
     barrier()
     if dist is not None:
         dist.destroy_process_group()
