@@ -669,6 +669,323 @@ __global__ __launch_bounds__(256) void k_match_screen(PairTable tbl, int npairs,
   }
 }
 
+// The screening passes again, arranged for the matrix cores' appetite (the form used by default):
+//  * a wave owns 64 queries (two B operands in registers), a block 256: every database row staged in
+//    LDS and every A operand read from it now feeds twice the matrix instructions, so the passes ask
+//    half as much of the L2 and of the LDS per score;
+//  * the database norm rides in the contraction: the rows get 16 more k-elements, three of which hold
+//    -|d|^2 / 2 split into bf16 parts (exact to 2^-27 of it), and the queries hold 1 there, so a matrix
+//    result is a = q.d - |d|^2 / 2 and the screening score is |q|^2 - 2 a. The epilogue thus only tracks
+//    the two LARGEST a per query (v_max + v_med3 per value) instead of building every score first
+//    (add + fma) and reading the norms from LDS. Rows beyond the database end carry -3e38 there and
+//    never win.
+// Same items otherwise (pair, database split, query tile), same per-(pair, split, query) outputs as
+// k_match_screen: the second smallest score (pass 0), the candidate list and its count (pass 1).
+constexpr int kQW2 = 64;                       // queries per wave
+constexpr float kPadNorm = -3.0e38f;           // norm part of the rows staged beyond the database end
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef const float __attribute__((address_space(1)))* GlobalF32;
+typedef const f32x4v __attribute__((address_space(1)))* GlobalF32x4;
+
+// The larger of two finite numbers in one instruction: fmaxf would first canonicalise both operands
+// (one more instruction each), which values that only ever meet comparisons do not need. (Not inline
+// assembly: the compiler does not track the wait states between a matrix instruction and an assembly
+// statement that reads its result.)
+__device__ __forceinline__ float max_raw(float a, float b)
+{
+    return __builtin_amdgcn_fmed3f(a, b, 3.4028234663852886e38f);
+}
+
+// WV waves per block: 4 (256 queries per work item; two blocks per compute unit) for batches of small
+// searches, 8 (512 queries, one block per compute unit) for large ones, where every staged database row
+// then serves twice the queries and the blocks ask half as much of the L2.
+template <int K, bool VEC, int PASS, int WV>
+__global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl, int npairs, int nq_cap, int nd_cap, int dim,
+                                                       int ld, const float* __restrict__ qn_all,
+                                                       const float* __restrict__ dn_all,
+                                                       const unsigned int* __restrict__ dnmax_all, int nsplit,
+                                                       float* __restrict__ t2_all, int* __restrict__ cnt_all,
+                                                       int* __restrict__ cand_all,
+                                                       unsigned int* __restrict__ work_counter)
+{
+    constexpr int KP = K + 16;                 // contraction length with the norm's k-step
+    constexpr int KS = KP / 16;                // matrix instructions per tile
+    constexpr int KPB = KP + 8;                // row pitch in bf16 elements (16 bytes of padding)
+    constexpr int K4 = K / 4;                  // float4 per staged row
+    constexpr int NT = 64 * WV;                // threads per block
+    constexpr int kQB2 = kQW2 * WV;            // queries per block and work item
+    constexpr int NV = kDC * K4 / NT;          // float4 staged per thread and chunk
+    constexpr int RSTEP = NT / K4;             // rows between a thread's consecutive float4
+    static_assert(NV >= 1 && NV * NT == kDC * K4, "staging: whole float4 per thread");
+    __shared__ __attribute__((aligned(16))) __bf16 s_b[2][kDC * KPB];
+    __shared__ int s_first[kMaxPairs + 1];
+    __shared__ int s_rows[kMaxPairs][2];
+    __shared__ int s_item;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int half = lane >> 5;
+    const int col = lane & 31;
+
+    for (int z = tid; z < kMaxPairs; z += NT) {
+        int cnt = 0;
+        if (z < npairs) {
+            const mif_match_pair& pz = tbl[z];
+            const int nqz = pz.d_nq ? min(*pz.d_nq, nq_cap) : nq_cap;
+            const int ndz = pz.d_nd ? min(*pz.d_nd, nd_cap) : nd_cap;
+            s_rows[z][0] = nqz;
+            s_rows[z][1] = ndz;
+            const int chunks = (ndz + kDC - 1) / kDC;
+            const int per = (chunks + nsplit - 1) / nsplit;
+            const int live = per > 0 ? (chunks + per - 1) / per : 0;         // splits that hold rows
+            cnt = ((nqz + kQB2 - 1) / kQB2) * live;
+        }
+        s_first[z + 1] = cnt;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        constexpr int PER = kMaxPairs / 64;
+        int c[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { c[j] = s_first[tid * PER + j + 1]; sum += c[j]; }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (tid >= d) incl += o;
+        }
+        int run = incl - sum;
+        if (tid == 0) s_first[0] = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { run += c[j]; s_first[tid * PER + j + 1] = run; }
+        if (tid == 0) s_item = (int)atomicAdd(work_counter, 1u);
+    }
+
+    const int k4 = tid % K4;
+    const int r0 = tid / K4;
+    const bool m0 = 4 * k4 + 0 < dim, m1 = 4 * k4 + 1 < dim, m2 = 4 * k4 + 2 < dim, m3 = 4 * k4 + 3 < dim;
+    const int kc0 = min(4 * k4 + 0, dim - 1), kc1 = min(4 * k4 + 1, dim - 1);
+    const int kc2 = min(4 * k4 + 2, dim - 1), kc3 = min(4 * k4 + 3, dim - 1);
+    const int k4c = m0 ? 4 * k4 : 0;
+
+  for (;;) {
+    __syncthreads();
+    const int item = __builtin_amdgcn_readfirstlane(s_item);
+    __syncthreads();
+    if (item >= s_first[kMaxPairs]) break;     // uniform over the block
+    int next_item = 0;
+    if (tid == 0) next_item = (int)atomicAdd(work_counter, 1u);
+    int z = 0;
+    {
+        int hi = npairs - 1;
+        while (z < hi) {
+            const int mid = (z + hi + 1) >> 1;
+            if (s_first[mid] <= item) z = mid; else hi = mid - 1;
+        }
+    }
+    z = __builtin_amdgcn_readfirstlane(z);
+    const mif_match_pair& pr = tbl[z];
+    const float* __restrict__ Q = pr.d_q;
+    const float* __restrict__ D = pr.d_db;
+    const float* __restrict__ qn = qn_all + (size_t)z * nq_cap;
+    const float* __restrict__ dn = dn_all + (size_t)z * nd_cap;
+    const int nq = __builtin_amdgcn_readfirstlane(s_rows[z][0]);
+    const int nd = __builtin_amdgcn_readfirstlane(s_rows[z][1]);
+    const int qtiles = (nq + kQB2 - 1) / kQB2;
+    const int split = (item - s_first[z]) / qtiles;             // consecutive items share database rows
+    const int qbase = ((item - s_first[z]) - split * qtiles) * kQB2 + wave * kQW2;
+    const int chunks = (nd + kDC - 1) / kDC;
+    const int per = (chunks + nsplit - 1) / nsplit;
+    const int c_lo = split * per;
+    const int c_hi = min(chunks, c_lo + per);
+    float* __restrict__ t2s = t2_all + (size_t)z * nsplit * nq_cap;
+    int* __restrict__ cnt = cnt_all + ((size_t)z * nsplit + split) * nq_cap;
+    int* __restrict__ cand = cand_all + ((size_t)z * nsplit + split) * nq_cap * kCandCap;
+
+    f32x4v stage[NV];
+    float stage_dn = 0.0f;
+    // (loads through global-address-space pointers: as generic pointers they would be flat loads, which
+    // also count as LDS operations and so make every wait for an LDS read wait for them too)
+    const GlobalF32 Dg = (GlobalF32)D;
+    const GlobalF32 dng = (GlobalF32)dn;
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int it = 0; it < NV; it++) {
+            const int j = min(c * kDC + r0 + RSTEP * it, nd - 1);
+            const GlobalF32 src = Dg + (size_t)j * ld;
+            if (VEC) stage[it] = *reinterpret_cast<GlobalF32x4>(src + k4c);
+            else stage[it] = (f32x4v){src[kc0], src[kc1], src[kc2], src[kc3]};
+        }
+        const int jr = c * kDC + (tid & (kDC - 1));
+        stage_dn = jr < nd ? -0.5f * dng[min(jr, nd - 1)] : kPadNorm;
+    };
+    // elements at and beyond dim are cleared after the conversion (two packed ANDs per four elements)
+    const uint32_t and01 = (m0 ? 0x0000ffffu : 0u) | (m1 ? 0xffff0000u : 0u);
+    const uint32_t and23 = (m2 ? 0x0000ffffu : 0u) | (m3 ? 0xffff0000u : 0u);
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < NV; it++) {
+            const int r = r0 + RSTEP * it;
+            uint2 u = __builtin_bit_cast(uint2, __builtin_convertvector(stage[it], bf16x4));
+            u.x &= and01; u.y &= and23;
+            *reinterpret_cast<uint2*>(&s_b[buf][r * KPB + 4 * k4]) = u;
+        }
+        if (tid < kDC) {
+            // the norm's k-step: -|d|^2 / 2 as three bf16 parts, then zeros
+            const __bf16 h1 = (__bf16)stage_dn;
+            const float r1 = stage_dn - (float)h1;
+            const __bf16 h2 = (__bf16)r1;
+            const __bf16 h3 = (__bf16)(r1 - (float)h2);
+            bf16x8 a, zz;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { a[i] = (__bf16)0.0f; zz[i] = (__bf16)0.0f; }
+            a[0] = h1; a[1] = h2; a[2] = h3;
+            *reinterpret_cast<bf16x8*>(&s_b[buf][tid * KPB + K]) = a;
+            *reinterpret_cast<bf16x8*>(&s_b[buf][tid * KPB + K + 8]) = zz;
+        }
+    };
+    load_chunk(c_lo);
+
+    // queries (B operands): lane holds q[qbase + 32 s + col][16 j + 8 half .. + 7] for every instruction j
+    bf16x8 qf[2][KS];
+    float qnv[2];
+    int qi[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+        qi[s2] = qbase + 32 * s2 + col;
+        const float* qr = Q + (size_t)min(qi[s2], nq - 1) * ld;
+        const bool row_ok = qi[s2] < nq;
+#pragma unroll
+        for (int j = 0; j < KS - 1; j++) {
+            const int k0 = 16 * j + 8 * half;
+            float e[8];
+            if (VEC) {
+                const float4 u = *reinterpret_cast<const float4*>(qr + min(k0, (dim - 1) & ~3));
+                const float4 w = *reinterpret_cast<const float4*>(qr + min(k0 + 4, (dim - 1) & ~3));
+                e[0] = u.x; e[1] = u.y; e[2] = u.z; e[3] = u.w; e[4] = w.x; e[5] = w.y; e[6] = w.z; e[7] = w.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) e[i] = qr[min(k0 + i, dim - 1)];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) qf[s2][j][i] = (__bf16)((row_ok && k0 + i < dim) ? e[i] : 0.0f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) qf[s2][KS - 1][i] = (__bf16)((row_ok && half == 0 && i < 3) ? 1.0f : 0.0f);
+        qnv[s2] = row_ok ? qn[qi[s2]] : 0.0f;
+    }
+    float t1[2] = {-kInf, -kInf}, t2[2] = {-kInf, -kInf};     // pass 0: the two largest a seen
+    // pass 1: a row is kept when its score |q|^2 - 2 a is at most the query's threshold, i.e. when
+    // a >= (|q|^2 - threshold) / 2. The second smallest score over all rows is at most the second
+    // smallest of any one split, so the smallest of the splits' values (+ 2 m) keeps every winner.
+    float alim[2] = {kInf, kInf};
+    int filled[2] = {0, 0};
+    if (PASS == 1) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            if (qi[s2] < nq) {
+                float t = kInf;
+                for (int sp = 0; sp * per < chunks; sp++) t = fminf(t, t2s[(size_t)sp * nq_cap + qi[s2]]);
+                const float dmax = __builtin_bit_cast(float, dnmax_all[z]);
+                const float m = kScreenRel * __builtin_sqrtf(qnv[s2] * dmax) + 3.0f * kScreenAbs * (qnv[s2] + dmax);
+                const float limit = t + 2.0f * m;       // +inf while no split holds two rows: every row is kept
+                alim[s2] = 0.5f * (qnv[s2] - limit);
+            }
+        }
+    }
+
+    auto consider = [&](const f32x16& acc, int jbase, int s2, bool full) {
+        if (PASS == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                t2[s2] = __builtin_amdgcn_fmed3f(t1[s2], t2[s2], acc[r]);     // t1 >= t2: the middle one is the new second
+                t1[s2] = max_raw(t1[s2], acc[r]);
+            }
+        } else {
+            float mx = acc[0];
+#pragma unroll
+            for (int r = 1; r < 16; r++) mx = max_raw(mx, acc[r]);
+            // A query's rows are seen by the two lanes l, l + 32 of this wave only, so its list is
+            // filled without atomics: the branch is uniform over the wave, the lower lane's rows of
+            // a tile go first, and both lanes keep the same running count.
+            if (__builtin_amdgcn_ballot_w64(mx >= alim[s2]) != 0ull) {
+                unsigned int hits = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; r++) hits |= (acc[r] >= alim[s2] ? 1u : 0u) << r;
+                if (!full) {                    // rows staged beyond the database end (they pass an infinite threshold)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        if (jbase + (r & 3) + 8 * (r >> 2) + 4 * half >= nd) hits &= ~(1u << r);
+                }
+                const int mine = __popc(hits);
+                const int other = __shfl_xor(mine, 32);
+                int at = filled[s2] + (half ? other : 0);
+                filled[s2] += mine + other;
+                while (hits != 0u) {
+                    const int r = __ffs((int)hits) - 1;
+                    hits &= hits - 1u;
+                    if (at < kCandCap) cand[(size_t)qi[s2] * kCandCap + at] = jbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    at++;
+                }
+            }
+        }
+    };
+    auto chunk_step = [&](int c, int buf) {
+        store_chunk(buf);
+        __syncthreads();
+        load_chunk(min(c + 1, c_hi - 1));
+        f32x16 acc00, acc01, acc10, acc11;      // [row tile][query set]
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc00[r] = 0.0f; acc01[r] = 0.0f; acc10[r] = 0.0f; acc11[r] = 0.0f; }
+        const __bf16* ap0 = &s_b[buf][col * KPB + 8 * half];
+        const __bf16* ap1 = &s_b[buf][(32 + col) * KPB + 8 * half];
+        // the A operands of k-step j + 1 are read from LDS while the matrix instructions of step j run
+        bf16x8 a = *reinterpret_cast<const bf16x8*>(ap0);
+        bf16x8 b = *reinterpret_cast<const bf16x8*>(ap1);
+#pragma unroll
+        for (int j = 0; j < KS; j++) {
+            bf16x8 an = a, bn = b;
+            if (j + 1 < KS) {
+                an = *reinterpret_cast<const bf16x8*>(ap0 + 16 * (j + 1));
+                bn = *reinterpret_cast<const bf16x8*>(ap1 + 16 * (j + 1));
+            }
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[0][j], acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[1][j], acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, qf[0][j], acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, qf[1][j], acc11, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // the two LDS reads of the next step ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // ... then this step's four matrix instructions
+            a = an; b = bn;
+        }
+        const bool full = (c + 1) * kDC <= nd;
+        consider(acc00, c * kDC, 0, full);
+        consider(acc01, c * kDC, 1, full);
+        consider(acc10, c * kDC + 32, 0, full);
+        consider(acc11, c * kDC + 32, 1, full);
+    };
+    for (int c = c_lo; c < c_hi; c += 2) {
+        chunk_step(c, 0);
+        if (c + 1 < c_hi) chunk_step(c + 1, 1);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+        if (PASS == 0) {
+            // lanes l and l + 32 hold the same query (interleaved database rows)
+            const float o1 = __shfl_xor(t1[s2], 32), o2 = __shfl_xor(t2[s2], 32);
+            float a1 = t1[s2], a2 = t2[s2];
+            a2 = __builtin_amdgcn_fmed3f(a1, a2, o1); a1 = fmaxf(a1, o1);
+            a2 = __builtin_amdgcn_fmed3f(a1, a2, o2); a1 = fmaxf(a1, o2);
+            // as a score; +inf when the split holds fewer than two rows (a2 = -inf or a padded row's -3e38)
+            if (half == 0 && qi[s2] < nq) t2s[(size_t)split * nq_cap + qi[s2]] = __builtin_fmaf(-2.0f, a2, qnv[s2]);
+        } else if (half == 0 && qi[s2] < nq) {
+            cnt[qi[s2]] = filled[s2];
+        }
+    }
+    if (tid == 0) s_item = next_item;
+  }
+}
+
 // Ranks the candidates of the screening passes with the exact search's arithmetic and writes the
 // two winners where k_match_partial would have written them (split 0), for k_match_finalize.
 // grid (ceil(nq_cap/128), npairs), one thread per query.
@@ -1023,10 +1340,26 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
                 float* thr = m->thr + (size_t)base * m->max_q;                    // per (pair, split, query)
                 int* ccnt = m->cand_cnt + (size_t)base * m->max_q;
                 int* cand = m->cand + (size_t)base * m->max_q * kCandCap;
+                static const bool screen_v1 = getenv("MIF_MATCH_SCREEN_V1") != nullptr;      // A/B switch
+                static const char* wide_env = getenv("MIF_MATCH_SCREEN_WIDE");               // A/B switch: 0 / 1
+                // 512 queries per work item where a pair has enough queries to fill such items and the
+                // database is large enough for its traffic to matter
+                const bool wide = wide_env ? atoi(wide_env) != 0 : (!device_counts && nq >= 16384 && nd >= 16384);
 #define MIF_LAUNCH_SCREEN(KK, V, PASS)                                                                           \
-    hipLaunchKernelGGL((k_match_screen<KK, V, PASS>), dim3(m->blocks), dim3(256), 0, st, tbl, np, nq, nd, dim, ld, \
-                       (const float*)qn, (const float*)dn, (const unsigned int*)nmax, nsplit, thr, ccnt, cand,  \
-                       m->work + 1 + PASS)
+    do {                                                                                                         \
+        if (screen_v1)                                                                                           \
+            hipLaunchKernelGGL((k_match_screen<KK, V, PASS>), dim3(m->blocks), dim3(256), 0, st, tbl, np, nq, nd, \
+                               dim, ld, (const float*)qn, (const float*)dn, (const unsigned int*)nmax, nsplit,   \
+                               thr, ccnt, cand, m->work + 1 + PASS);                                             \
+        else if (wide)                                                                                           \
+            hipLaunchKernelGGL((k_match_screen2<KK, V, PASS, 8>), dim3(m->blocks / 2), dim3(512), 0, st, tbl, np,  \
+                               nq, nd, dim, ld, (const float*)qn, (const float*)dn, (const unsigned int*)nmax,   \
+                               nsplit, thr, ccnt, cand, m->work + 1 + PASS);                                     \
+        else                                                                                                     \
+            hipLaunchKernelGGL((k_match_screen2<KK, V, PASS, 4>), dim3(m->blocks), dim3(256), 0, st, tbl, np,    \
+                               nq, nd, dim, ld, (const float*)qn, (const float*)dn, (const unsigned int*)nmax,   \
+                               nsplit, thr, ccnt, cand, m->work + 1 + PASS);                                     \
+    } while (0)
                 if (dim <= 64) {
                     if (vec) { MIF_LAUNCH_SCREEN(64, true, 0); MIF_LAUNCH_SCREEN(64, true, 1); }
                     else     { MIF_LAUNCH_SCREEN(64, false, 0); MIF_LAUNCH_SCREEN(64, false, 1); }

@@ -42,3 +42,15 @@ def test_scale_space_levels_singly_or_in_pairs(tmp_path, mask):
     alt = _run(tmp_path, "pairs" + mask, {"MIF_BLUR_PAIRS": mask})
     for k in ref.files:
         assert ref[k].shape == alt[k].shape and ref[k].tobytes() == alt[k].tobytes(), k
+
+
+@pytest.mark.parametrize("env", [{"MIF_MATCH_SCREEN_V1": "1"}, {"MIF_MATCH_SCREEN_WIDE": "1"},
+                                 {"MIF_MATCH_SCREEN_WIDE": "0"}])
+def test_screening_kernel_forms(tmp_path, env):
+    """The screening passes exist in three forms (32 queries per wave with the norms added in the epilogue;
+    64 queries per wave with the norms inside the contraction, in blocks of 4 or of 8 waves): each must give
+    the default's bits."""
+    ref = _run(tmp_path, "default", {})
+    alt = _run(tmp_path, "screen", env)
+    for k in ("match_idx", "match_dist"):
+        assert ref[k].shape == alt[k].shape and ref[k].tobytes() == alt[k].tobytes(), k
