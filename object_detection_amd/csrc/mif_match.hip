@@ -805,6 +805,7 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
 
     f32x4v stage[NV];
     float stage_dn = 0.0f;
+    bool stage_pad = false;
     // (loads through global-address-space pointers: as generic pointers they would be flat loads, which
     // also count as LDS operations and so make every wait for an LDS read wait for them too)
     const GlobalF32 Dg = (GlobalF32)D;
@@ -817,8 +818,10 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
             if (VEC) stage[it] = *reinterpret_cast<GlobalF32x4>(src + k4c);
             else stage[it] = (f32x4v){src[kc0], src[kc1], src[kc2], src[kc3]};
         }
+        // (only loaded here; anything computed from it now would wait for all the loads above)
         const int jr = c * kDC + (tid & (kDC - 1));
-        stage_dn = jr < nd ? -0.5f * dng[min(jr, nd - 1)] : kPadNorm;
+        stage_dn = dng[min(jr, nd - 1)];
+        stage_pad = jr >= nd;
     };
     // elements at and beyond dim are cleared after the conversion (two packed ANDs per four elements)
     const uint32_t and01 = (m0 ? 0x0000ffffu : 0u) | (m1 ? 0xffff0000u : 0u);
@@ -833,8 +836,9 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
         }
         if (tid < kDC) {
             // the norm's k-step: -|d|^2 / 2 as three bf16 parts, then zeros
-            const __bf16 h1 = (__bf16)stage_dn;
-            const float r1 = stage_dn - (float)h1;
+            const float hn = stage_pad ? kPadNorm : -0.5f * stage_dn;
+            const __bf16 h1 = (__bf16)hn;
+            const float r1 = hn - (float)h1;
             const __bf16 h2 = (__bf16)r1;
             const __bf16 h3 = (__bf16)(r1 - (float)h2);
             bf16x8 a, zz;
@@ -983,6 +987,361 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
         }
     }
     if (tid == 0) s_item = next_item;
+  }
+}
+
+// ---- screening on a bf16 copy of the database, staged by LDS-DMA, the waves of a SIMD working in turns
+//
+// In k_match_screen2 the two waves that share a SIMD (one of each of a compute unit's two blocks) fall into
+// step: both issue their matrix instructions at the same time, at half speed each, and then both run
+// their vector work while the matrix pipe idles (42 % of the wave cycles waiting for an issue slot, the
+// pipe busy 47 %). Here a block has 8 waves, two per SIMD (waves w and w + 4 share one), and its halves
+// alternate between a matrix phase (the matrix instructions of a chunk) and a vector phase (the epilogue
+// of their previous chunk), half a chunk apart, with a barrier between the half periods:
+//     half period 2c     : waves 0-3 matrix(c)   | waves 4-7 epilogue(c - 1)
+//     half period 2c + 1 : waves 0-3 epilogue(c) | waves 4-7 matrix(c)
+// The vector phase has to be short for that, and the registers few (two waves per SIMD leave 256 each,
+// and 64 accumulators + 72 of B operands are given): so the staging does not go through registers. The
+// database rows are converted ONCE per search into a bf16 image that is what a chunk looks like in LDS
+// (k_match_pack_rows: pitch K + 24 elements, the norm's k-step included, rows padded to whole chunks), and
+// a chunk is then 19 (11 for K = 64) wave-wide 1 KB copies straight into LDS (global_load_lds_dwordx4: the
+// LDS address is a wave-uniform base + 16 bytes per lane, the image is contiguous on both sides), issued
+// at the start of half period 2c for chunk c + 1 and waited for before the barrier that ends 2c + 1.
+// All LDS of the kernel is one array: a second __shared__ object beside a DMA target can make the
+// compiler wait for the DMA before every LDS read. The barriers of the loop are raw s_barrier: a
+// __syncthreads() would drain the copy in flight.
+
+// The bf16 image of the database rows of every pair: [pair][rows_pad][K + 24], rows_pad a multiple of the
+// chunk size. Element k < K: bf16(d[k]) (0 at and beyond dim); K .. K + 2: -|d|^2 / 2 in three bf16 parts
+// (kPadNorm for rows at and beyond the pair's row count, which therefore never win); the rest 0.
+// One thread per 16-byte piece of a row. grid (ceil(rows_pad * pieces / 256), pairs).
+template <int K, bool VEC>
+__global__ __launch_bounds__(256) void k_match_pack_rows(PairTable tbl, int nd_cap, int rows_pad, int dim, int ld,
+                                                         const float* __restrict__ dn_all, __bf16* __restrict__ out_all)
+{
+    constexpr int KPB = K + 24;
+    constexpr int NP = KPB / 8;                // 16-byte pieces per row
+    const mif_match_pair& pr = tbl[blockIdx.y];
+    const int nd = pr.d_nd ? min(*pr.d_nd, nd_cap) : nd_cap;
+    const int rows = ((nd + kDC - 1) / kDC) * kDC;          // the chunks the search will read
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = t / NP, p = t - j * NP;
+    if (j >= rows) return;
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (__bf16)0.0f;
+    if (p < K / 8) {
+        if (j < nd) {
+            const float* r = pr.d_db + (size_t)j * ld;
+            float e[8];
+            if (VEC && 8 * p + 8 <= ld) {
+                const float4 u = *reinterpret_cast<const float4*>(r + 8 * p);
+                const float4 w = *reinterpret_cast<const float4*>(r + 8 * p + 4);
+                e[0] = u.x; e[1] = u.y; e[2] = u.z; e[3] = u.w; e[4] = w.x; e[5] = w.y; e[6] = w.z; e[7] = w.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) e[i] = (8 * p + i < dim) ? r[8 * p + i] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = (__bf16)((8 * p + i < dim) ? e[i] : 0.0f);
+        }
+    } else if (p == K / 8) {
+        const float hn = j < nd ? -0.5f * dn_all[(size_t)blockIdx.y * nd_cap + j] : kPadNorm;
+        const __bf16 h1 = (__bf16)hn;
+        const float r1 = hn - (float)h1;
+        const __bf16 h2 = (__bf16)r1;
+        v[0] = h1; v[1] = h2; v[2] = (__bf16)(r1 - (float)h2);
+    }
+    *reinterpret_cast<bf16x8*>(out_all + ((size_t)blockIdx.y * rows_pad + j) * KPB + 8 * p) = v;
+}
+
+// The largest of three as the bare instruction. The compiler does not track the wait states between a
+// matrix instruction and an assembly statement that reads its result: the first use of every accumulator
+// must be an ordinary expression (max_raw), which this may then follow through a data dependence.
+__device__ __forceinline__ float max3_raw(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+typedef const char __attribute__((address_space(1)))* GlobalBytes;
+typedef char __attribute__((address_space(3)))* LdsBytes;
+
+template <int K, bool VEC, int PASS>
+__global__ __launch_bounds__(512, 1) void k_match_screen4(PairTable tbl, int npairs, int nq_cap, int nd_cap, int dim,
+                                                          int ld, const float* __restrict__ qn_all,
+                                                          const __bf16* __restrict__ dbf_all, int rows_pad,
+                                                          const unsigned int* __restrict__ dnmax_all, int nsplit,
+                                                          float* __restrict__ t2_all, int* __restrict__ cnt_all,
+                                                          int* __restrict__ cand_all,
+                                                          unsigned int* __restrict__ work_counter)
+{
+    constexpr int KP = K + 16;                 // contraction length with the norm's k-step
+    constexpr int KS = KP / 16;                // matrix instructions per tile
+    constexpr int KPB = K + 24;                // row pitch in bf16 elements (16 bytes of padding)
+    constexpr int WV = 8;
+    constexpr int NT = 64 * WV;                // threads per block
+    constexpr int kQB = kQW2 * WV;             // queries per block and work item
+    constexpr int kChunkBytes = kDC * KPB * 2;
+    constexpr int kPieces = kChunkBytes / 1024;             // wave-wide copies per chunk
+    static_assert(kPieces * 1024 == kChunkBytes, "a chunk is a whole number of wave-wide copies");
+    // one LDS array: the two chunk buffers, then the item tables
+    constexpr int kOffFirst = 2 * kChunkBytes;
+    constexpr int kOffRows = kOffFirst + (kMaxPairs + 1) * 4;
+    constexpr int kOffItem = kOffRows + kMaxPairs * 2 * 4;
+    __shared__ __attribute__((aligned(1024))) char s_all[kOffItem + 16];
+    int* const s_first = reinterpret_cast<int*>(s_all + kOffFirst);
+    int (*const s_rows)[2] = reinterpret_cast<int (*)[2]>(s_all + kOffRows);
+    int* const s_item = reinterpret_cast<int*>(s_all + kOffItem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int col = lane & 31;
+    const int group = wave >> 2;               // 0: matrix phase first, 1: half a chunk later
+
+    for (int z = tid; z < kMaxPairs; z += NT) {
+        int cnt = 0;
+        if (z < npairs) {
+            const mif_match_pair& pz = tbl[z];
+            const int nqz = pz.d_nq ? min(*pz.d_nq, nq_cap) : nq_cap;
+            const int ndz = pz.d_nd ? min(*pz.d_nd, nd_cap) : nd_cap;
+            s_rows[z][0] = nqz;
+            s_rows[z][1] = ndz;
+            const int chunks = (ndz + kDC - 1) / kDC;
+            const int per = (chunks + nsplit - 1) / nsplit;
+            const int live = per > 0 ? (chunks + per - 1) / per : 0;         // splits that hold rows
+            cnt = ((nqz + kQB - 1) / kQB) * live;
+        }
+        s_first[z + 1] = cnt;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        constexpr int PER = kMaxPairs / 64;
+        int c[PER], sum = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { c[j] = s_first[tid * PER + j + 1]; sum += c[j]; }
+        int incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (tid >= d) incl += o;
+        }
+        int run = incl - sum;
+        if (tid == 0) s_first[0] = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { run += c[j]; s_first[tid * PER + j + 1] = run; }
+        if (tid == 0) *s_item = (int)atomicAdd(work_counter, 1u);
+    }
+
+  for (;;) {
+    __syncthreads();
+    const int item = __builtin_amdgcn_readfirstlane(*s_item);
+    __syncthreads();
+    if (item >= s_first[kMaxPairs]) break;     // uniform over the block
+    int next_item = 0;
+    if (tid == 0) next_item = (int)atomicAdd(work_counter, 1u);
+    int z = 0;
+    {
+        int hi = npairs - 1;
+        while (z < hi) {
+            const int mid = (z + hi + 1) >> 1;
+            if (s_first[mid] <= item) z = mid; else hi = mid - 1;
+        }
+    }
+    z = __builtin_amdgcn_readfirstlane(z);
+    const mif_match_pair& pr = tbl[z];
+    const float* __restrict__ Q = pr.d_q;
+    const float* __restrict__ qn = qn_all + (size_t)z * nq_cap;
+    const int nq = __builtin_amdgcn_readfirstlane(s_rows[z][0]);
+    const int nd = __builtin_amdgcn_readfirstlane(s_rows[z][1]);
+    const int qtiles = (nq + kQB - 1) / kQB;
+    const int split = (item - s_first[z]) / qtiles;             // consecutive items share database rows
+    const int qbase = ((item - s_first[z]) - split * qtiles) * kQB + wave * kQW2;
+    const int chunks = (nd + kDC - 1) / kDC;
+    const int per = (chunks + nsplit - 1) / nsplit;
+    const int c_lo = split * per;
+    const int c_hi = min(chunks, c_lo + per);
+    float* __restrict__ t2s = t2_all + (size_t)z * nsplit * nq_cap;
+    int* __restrict__ cnt = cnt_all + ((size_t)z * nsplit + split) * nq_cap;
+    int* __restrict__ cand = cand_all + ((size_t)z * nsplit + split) * nq_cap * kCandCap;
+    // the pair's bf16 image; a chunk is kChunkBytes contiguous bytes of it
+    const GlobalBytes image = (GlobalBytes)(dbf_all + (size_t)z * rows_pad * KPB);
+    // chunk c into buffer buf: this wave's share of the wave-wide copies, pieces first, first + step, ...
+    auto copy_chunk = [&](int c, int buf, int first, int step) {
+        const GlobalBytes src = image + (size_t)c * kChunkBytes + lane * 16;
+#pragma unroll
+        for (int p0 = 0; p0 < kPieces + 8; p0 += 4) {       // (step is 4 or 8: at most kPieces / 4 + 1 pieces per wave)
+            const int p = first + (p0 >> 2) * step;
+            if (p < kPieces)
+                __builtin_amdgcn_global_load_lds(src + p * 1024, (LdsBytes)(s_all + buf * kChunkBytes + p * 1024), 16, 0, 0);
+        }
+    };
+    copy_chunk(c_lo, 0, wave, WV);
+
+    // queries (B operands): lane holds q[qbase + 32 s + col][16 j + 8 half .. + 7] for every instruction j
+    bf16x8 qf[2][KS];
+    float qnv[2];
+    int qi[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+        qi[s2] = qbase + 32 * s2 + col;
+        const float* qr = Q + (size_t)min(qi[s2], nq - 1) * ld;
+        const bool row_ok = qi[s2] < nq;
+#pragma unroll
+        for (int j = 0; j < KS - 1; j++) {
+            const int k0 = 16 * j + 8 * half;
+            float e[8];
+            if (VEC) {
+                const float4 u = *reinterpret_cast<const float4*>(qr + min(k0, (dim - 1) & ~3));
+                const float4 w = *reinterpret_cast<const float4*>(qr + min(k0 + 4, (dim - 1) & ~3));
+                e[0] = u.x; e[1] = u.y; e[2] = u.z; e[3] = u.w; e[4] = w.x; e[5] = w.y; e[6] = w.z; e[7] = w.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) e[i] = qr[min(k0 + i, dim - 1)];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) qf[s2][j][i] = (__bf16)((row_ok && k0 + i < dim) ? e[i] : 0.0f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) qf[s2][KS - 1][i] = (__bf16)((row_ok && half == 0 && i < 3) ? 1.0f : 0.0f);
+        qnv[s2] = row_ok ? qn[qi[s2]] : 0.0f;
+    }
+    // pass 0: the largest a seen among the rows of the chunks' first row tiles and among those of their
+    // second row tiles. The smaller of the two maxima belongs to a row other than the overall best one, so
+    // as a score it is at least the second smallest score: a threshold as valid as the second smallest
+    // itself (a little looser: it is the second smallest whenever the two best rows sit in different
+    // tiles) for a quarter of the vector instructions (one v_max3 per two values).
+    float t1[2] = {-kInf, -kInf}, t2[2] = {-kInf, -kInf};
+    // pass 1: a row is kept when its score |q|^2 - 2 a is at most the query's threshold, i.e. when
+    // a >= (|q|^2 - threshold) / 2. The second smallest score over all rows is at most the second
+    // smallest of any one split, so the smallest of the splits' values (+ 2 m) keeps every winner.
+    float alim[2] = {kInf, kInf};
+    int filled[2] = {0, 0};
+    if (PASS == 1) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; s2++) {
+            if (qi[s2] < nq) {
+                float t = kInf;
+                for (int sp = 0; sp * per < chunks; sp++) t = fminf(t, t2s[(size_t)sp * nq_cap + qi[s2]]);
+                const float dmax = __builtin_bit_cast(float, dnmax_all[z]);
+                const float m = kScreenRel * __builtin_sqrtf(qnv[s2] * dmax) + 3.0f * kScreenAbs * (qnv[s2] + dmax);
+                const float limit = t + 2.0f * m;       // +inf while no split holds two rows: every row is kept
+                alim[s2] = 0.5f * (qnv[s2] - limit);
+            }
+        }
+    }
+
+    auto consider = [&](const f32x16& acc, int jbase, int s2, bool full) {
+        if (PASS == 0) {
+            float& t = (jbase & 32) ? t2[s2] : t1[s2];
+            t = max_raw(t, acc[0]);
+#pragma unroll
+            for (int r = 1; r < 15; r += 2) t = max3_raw(t, acc[r], acc[r + 1]);
+            t = max_raw(t, acc[15]);
+        } else {
+            float mx = max_raw(acc[0], acc[1]);
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) mx = max3_raw(mx, acc[r], acc[r + 1]);
+            // A query's rows are seen by the two lanes l, l + 32 of this wave only, so its list is
+            // filled without atomics: the branch is uniform over the wave, the lower lane's rows of
+            // a tile go first, and both lanes keep the same running count.
+            if (__builtin_amdgcn_ballot_w64(mx >= alim[s2]) != 0ull) {
+                unsigned int hits = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; r++) hits |= (acc[r] >= alim[s2] ? 1u : 0u) << r;
+                if (!full) {                    // rows staged beyond the database end (they pass an infinite threshold)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        if (jbase + (r & 3) + 8 * (r >> 2) + 4 * half >= nd) hits &= ~(1u << r);
+                }
+                const int mine = __popc(hits);
+                const int other = __shfl_xor(mine, 32);
+                int at = filled[s2] + (half ? other : 0);
+                filled[s2] += mine + other;
+                while (hits != 0u) {
+                    const int r = __ffs((int)hits) - 1;
+                    hits &= hits - 1u;
+                    if (at < kCandCap) cand[(size_t)qi[s2] * kCandCap + at] = jbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    at++;
+                }
+            }
+        }
+    };
+    f32x16 acc00, acc01, acc10, acc11;          // [row tile][query set] of the chunk last multiplied
+    auto matrix_phase = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) { acc00[r] = 0.0f; acc01[r] = 0.0f; acc10[r] = 0.0f; acc11[r] = 0.0f; }
+        const __bf16* ap0 = reinterpret_cast<const __bf16*>(s_all + buf * kChunkBytes) + col * KPB + 8 * half;
+        const __bf16* ap1 = ap0 + 32 * KPB;
+        // the A operands are read from LDS two k-steps ahead of the matrix instructions that use them
+        // (one step ahead, 128 cycles, did not cover the LDS latency under load: the matrix pipe was busy
+        // for 56 % of a matrix phase)
+        bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap0);
+        bf16x8 b0 = *reinterpret_cast<const bf16x8*>(ap1);
+        bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap0 + 16);
+        bf16x8 b1 = *reinterpret_cast<const bf16x8*>(ap1 + 16);
+        // the order the scheduler must keep: the four reads above, then per k-step its four matrix
+        // instructions followed by the two reads for two steps later
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int j = 0; j < KS; j++) {
+            bf16x8 a2 = a1, b2 = b1;
+            if (j + 2 < KS) {
+                a2 = *reinterpret_cast<const bf16x8*>(ap0 + 16 * (j + 2));
+                b2 = *reinterpret_cast<const bf16x8*>(ap1 + 16 * (j + 2));
+            }
+            acc00 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[0][j], acc00, 0, 0, 0);
+            acc01 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[1][j], acc01, 0, 0, 0);
+            acc10 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, qf[0][j], acc10, 0, 0, 0);
+            acc11 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, qf[1][j], acc11, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (j + 2 < KS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            a0 = a1; b0 = b1; a1 = a2; b1 = b2;
+        }
+    };
+    auto vector_phase = [&](int c) {            // epilogue of chunk c
+        const bool full = (c + 1) * kDC <= nd;
+        consider(acc00, c * kDC, 0, full);
+        consider(acc01, c * kDC, 1, full);
+        consider(acc10, c * kDC + 32, 0, full);
+        consider(acc11, c * kDC + 32, 1, full);
+    };
+    // chunk c_lo has to be in LDS before the first matrix phase
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int c = c_lo; c < c_hi; c++) {
+        const int buf = (c - c_lo) & 1;
+        // The next chunk is fetched by the half that is in its (shorter) vector phase: issuing a copy
+        // costs a wave 60-180 cycles, which the matrix phase cannot spare. Its buffer was last read in
+        // half period 2c - 1.
+        if (group == 0) {
+            matrix_phase(buf);
+        } else {
+            if (c + 1 < c_hi) copy_chunk(c + 1, buf ^ 1, wave - 4, 4);
+            if (c > c_lo) vector_phase(c - 1);
+        }
+        __builtin_amdgcn_s_barrier();
+        if (group == 0) vector_phase(c);
+        else matrix_phase(buf);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the pieces of chunk c + 1 this wave issued have landed
+        __builtin_amdgcn_s_barrier();
+    }
+    if (group == 1) vector_phase(c_hi - 1);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; s2++) {
+        if (PASS == 0) {
+            // lanes l and l + 32 hold the same query (interleaved database rows)
+            const float a1 = fmaxf(t1[s2], __shfl_xor(t1[s2], 32));
+            const float a2 = fminf(a1, fmaxf(t2[s2], __shfl_xor(t2[s2], 32)));
+            // as a score; +inf when a tile class holds no row (a2 = -inf or a padded row's -3e38)
+            if (half == 0 && qi[s2] < nq) t2s[(size_t)split * nq_cap + qi[s2]] = __builtin_fmaf(-2.0f, a2, qnv[s2]);
+        } else if (half == 0 && qi[s2] < nq) {
+            cnt[qi[s2]] = filled[s2];
+        }
+    }
+    if (tid == 0) *s_item = next_item;
   }
 }
 
@@ -1201,6 +1560,9 @@ struct mif_matcher {
     int* cand_cnt = nullptr;
     int* cand = nullptr;            // [screen_slots][kCandCap]
     size_t screen_slots = 0;
+    // bf16 image of the database rows for the screening passes (k_match_pack_rows): [pairs][rows_pad][152]
+    __bf16* dbf = nullptr;
+    int rows_pad = 0;
     // pair tables: pinned host copies and their device twins, used in rotation; a slot is reused
     // once the call that read it last has finished on the GPU (slot_ev)
     mif_match_pair* h_tbl[kTableSlots] = {};
@@ -1219,6 +1581,12 @@ constexpr int kMaxSplit = 64;
 // the two extra launches cost more than the cheaper arithmetic saves.
 constexpr double kScreenMinScores = 3.2e7;
 constexpr int kScreenSplitRows = 32768;     // most rows of a database split under screening
+// The screening passes through the bf16 image (k_match_pack_rows, k_match_screen4) pay for the image and for
+// their long start of a work item only on large searches: measured against k_match_screen2 they lose up to
+// 65536 x 65536 rows, draw at 65536 x 262144 and win 10 % at 1 M x 1 M. Row counts known on the host only.
+constexpr double kTurnsMinScores = 1.5e10;
+constexpr int kTurnsMinQueries = 16384;
+constexpr int kTurnsMinRows = 65536;
 
 void free_matcher(mif_matcher* m)
 {
@@ -1226,6 +1594,7 @@ void free_matcher(mif_matcher* m)
     (void)hipFree(m->d_q); (void)hipFree(m->d_db); (void)hipFree(m->d_idx); (void)hipFree(m->d_dist);
     (void)hipFree(m->d_score); (void)hipFree(m->work);
     (void)hipFree(m->dnmax); (void)hipFree(m->thr); (void)hipFree(m->cand_cnt); (void)hipFree(m->cand);
+    (void)hipFree(m->dbf);
     for (int i = 0; i < kTableSlots; i++) {
         if (m->h_tbl[i]) (void)hipHostFree(m->h_tbl[i]);
         (void)hipFree(m->d_tbl[i]);
@@ -1344,13 +1713,27 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
                 static const char* wide_env = getenv("MIF_MATCH_SCREEN_WIDE");               // A/B switch: 0 / 1
                 // 512 queries per work item where a pair has enough queries to fill such items and the
                 // database is large enough for its traffic to matter
-                const bool wide = wide_env ? atoi(wide_env) != 0 : (!device_counts && nq >= 16384 && nd >= 16384);
+                const bool wide = wide_env ? atoi(wide_env) != 0 : false;
+                static const char* turns_env = getenv("MIF_MATCH_SCREEN_TURNS");             // A/B switch: 0 / 1
+                const bool large = !device_counts && nq >= kTurnsMinQueries && nd >= kTurnsMinRows &&
+                                   (double)nq * nd >= kTurnsMinScores;
+                const bool turns = m->dbf != nullptr && (turns_env ? atoi(turns_env) != 0 : large);
+                __bf16* dbf = m->dbf ? m->dbf + (size_t)base * m->rows_pad * (128 + 24) : nullptr;
 #define MIF_LAUNCH_SCREEN(KK, V, PASS)                                                                           \
     do {                                                                                                         \
         if (screen_v1)                                                                                           \
             hipLaunchKernelGGL((k_match_screen<KK, V, PASS>), dim3(m->blocks), dim3(256), 0, st, tbl, np, nq, nd, \
                                dim, ld, (const float*)qn, (const float*)dn, (const unsigned int*)nmax, nsplit,   \
                                thr, ccnt, cand, m->work + 1 + PASS);                                             \
+        else if (turns) {                                                                                        \
+            if (PASS == 0)                                                                                       \
+                hipLaunchKernelGGL((k_match_pack_rows<KK, V>),                                                   \
+                                   dim3((unsigned)(((size_t)m->rows_pad * ((KK + 24) / 8) + 255) / 256), np),   \
+                                   dim3(256), 0, st, tbl, nd, m->rows_pad, dim, ld, (const float*)dn, dbf);      \
+            hipLaunchKernelGGL((k_match_screen4<KK, V, PASS>), dim3(m->blocks / 2), dim3(512), 0, st, tbl, np,  \
+                               nq, nd, dim, ld, (const float*)qn, (const __bf16*)dbf, m->rows_pad,              \
+                               (const unsigned int*)nmax, nsplit, thr, ccnt, cand, m->work + 1 + PASS);          \
+        }                                                                                                        \
         else if (wide)                                                                                           \
             hipLaunchKernelGGL((k_match_screen2<KK, V, PASS, 8>), dim3(m->blocks / 2), dim3(512), 0, st, tbl, np,  \
                                nq, nd, dim, ld, (const float*)qn, (const float*)dn, (const unsigned int*)nmax,   \
@@ -1556,6 +1939,17 @@ int mif_match_create_batched(int device, int max_query, int max_database, int ma
     if ((e = hipMalloc(&m->thr, m->screen_slots * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->cand_cnt, m->screen_slots * sizeof(int))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->cand, m->screen_slots * kCandCap * sizeof(int))) != hipSuccess) return fail(e);
+    // the bf16 image of the database rows for the screening passes of large searches (kTurnsMinScores);
+    // a matcher too small for those has none, and without it (out of memory) the passes stage the fp32
+    // rows themselves
+    m->rows_pad = (max_database + kDC - 1) / kDC * kDC;
+    const bool large = max_query >= kTurnsMinQueries && max_database >= kTurnsMinRows &&
+                       (double)max_query * max_database >= kTurnsMinScores;
+    if ((large || getenv("MIF_MATCH_SCREEN_TURNS")) &&
+        hipMalloc(&m->dbf, P * (size_t)m->rows_pad * (128 + 24) * sizeof(__bf16)) != hipSuccess) {
+        (void)hipGetLastError();
+        m->dbf = nullptr;
+    }
     for (int i = 0; i < kTableSlots; i++) {
         if ((e = hipHostMalloc(&m->h_tbl[i], P * sizeof(mif_match_pair))) != hipSuccess) return fail(e);
         if ((e = hipMalloc(&m->d_tbl[i], P * sizeof(mif_match_pair))) != hipSuccess) return fail(e);
