@@ -1350,9 +1350,11 @@ __device__ __forceinline__ void desc_accumulate(float* __restrict__ d, float nx,
 // folds into bin 0 and the 8 histograms of a cell are summed in lane order.
 // Normalisation sums the 128 squares sequentially, as the reference's
 // one-thread-per-keypoint kernel does.
-// PLAIN: every window goes through the general loop (the form kept for comparison); otherwise waves
-// whose windows are all at least 8 pixels wide take the streamlined loop below.
-template <bool PLAIN>
+// MODE 0: every window goes through the general loop (the form kept for comparison). MODE 1: waves whose
+// windows are all at least 8 pixels wide take the streamlined loop below. MODE 2: such waves whose windows
+// are also at most 128 x 128 pixels first mark the pixels that pass the cell test (a loop without gathers
+// or histogram work) and then visit only those.
+template <int MODE>
 __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ kp, const float* __restrict__ orient,
                                                     const float2* __restrict__ grad, size_t grad_stride, int w, int h,
                                                     int o, int cap, const int* __restrict__ counts,
@@ -1414,7 +1416,79 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
     // a lane is inside its window exactly while its row is, and the gathers go through a buffer
     // descriptor of the level's plane, whose range check makes the look-ahead of lanes that have left
     // their window harmless (they read 0 and accumulate nothing). The plane must fit a 32-bit offset.
-    if (!PLAIN && __all(wx >= 8 && hy > 0) && (size_t)w * h < ((size_t)1 << 29)) {
+    const bool wide = MODE != 0 && __all(wx >= 8 && hy > 0) && (size_t)w * h < ((size_t)1 << 29);
+    if (MODE == 2 && wide && __all(wx <= 128 && hy <= 128) && w < (1 << 16)) {
+        // Two phases per 32 rounds of the walk. Phase 1 runs the walk and the cell test alone and leaves
+        // bit j of `mask` set when the lane's pixel of round j passes. Phase 2 visits the set bits in
+        // ascending order (the order in which the reference's work-item adds to its histogram): window
+        // pixel i = lid + 8 (base + j) lies in row i / wx and column i % wx, found as
+        // floor((i + 0.5) / wx) in float: with wx and the row at most 128 the product is off by less than
+        // 2e-5 while the exact quotient is at least 0.5 / 128 away from an integer, so the floor is exact.
+        // About 40 % of a window's pixels fail the test and cost the first phase only.
+        const uint32_t lvl = __builtin_amdgcn_readfirstlane((uint32_t)((int)((float)(w * h) * f4.w) - w * h));
+        const float2* plane = grad + lvl;
+        const uint64_t pb = (uint64_t)plane;
+        const uint32_t pb_lo = __builtin_amdgcn_readfirstlane((uint32_t)pb);
+        const uint32_t pb_hi = __builtin_amdgcn_readfirstlane((uint32_t)(pb >> 32));
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(((uint64_t)pb_hi << 32) | pb_lo), 0,
+                                                            (int)((uint32_t)(w * h) * 8u), 0x00020000);
+        const float fxmax = (float)xmax, fymax = (float)ymax, fwx = (float)wx, fw = (float)w;
+        const float fxmin = (float)xmin, fymin = (float)ymin;
+        const float rwx = 1.0f / fwx, hrwx = 0.5f * rwx;
+        const uint32_t boff0 = (uint32_t)(ymin * w + xmin) * 8u;
+        float fx = (float)(xmin + lid), fy = (float)ymin;
+        float fbase = (float)lid;                           // window pixel index of this lane in round `base`
+        // a lane's rounds: ceil((loops - lid) / 8); the wave runs to its longest lane
+        int most = (loops - lid + 7) >> 3;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) most = max(most, __shfl_xor(most, m, 64));
+        most = __builtin_amdgcn_readfirstlane(most);
+        for (int base = 0; base < most; base += 32, fbase += 256.0f) {
+            const int nj = min(32, most - base);
+            uint32_t mask = 0;
+            for (int j = 0; j < nj; j++) {
+                const float dx = fx - ptx;
+                const float dy = fy - pty;
+                const float nx = crspt * dx + srspt * dy;
+                const float ny = crspt * dy - srspt * dx;
+                const bool pass = (int)(fy <= fymax) & (int)(mif_fabsf(nx) < 1.0f) & (int)(mif_fabsf(ny) < 1.0f);
+                mask |= pass ? (1u << j) : 0u;
+                fx += 8.0f;
+                const bool wrap = fx > fxmax;
+                fx -= wrap ? fwx : 0.0f;
+                fy += wrap ? 1.0f : 0.0f;
+            }
+            // phase 2, the gather of the next marked pixel in flight while the current one is accumulated
+            float ncx, ncy;
+            v2f gn;
+            bool nact;
+            auto decode = [&]() {
+                nact = mask != 0;
+                const int j = __builtin_ctz(mask | 0x80000000u);
+                mask &= mask - 1;
+                const float fi = fbase + (float)(j << 3);
+                const float q = __builtin_floorf(__builtin_fmaf(fi, rwx, hrwx));
+                const float r = __builtin_fmaf(-q, fwx, fi);
+                ncx = r + fxmin;
+                ncy = q + fymin;
+                const uint32_t boff = boff0 + (uint32_t)__builtin_fmaf(q, fw, r) * 8u;
+                // lanes without a marked pixel left read beyond the plane: the range check returns 0
+                gn = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, nact ? boff : 0xfffffff8u, 0, 0));
+            };
+            decode();
+            while (__any(nact)) {
+                const float cfx = ncx, cfy = ncy;
+                const v2f g = gn;
+                const bool act = nact;
+                decode();
+                const float dx = cfx - ptx;
+                const float dy = cfy - pty;
+                const float nx = crspt * dx + srspt * dy;
+                const float ny = crspt * dy - srspt * dx;
+                if (act) desc_accumulate(d, nx, ny, make_float2(g.x, g.y), offx, offy, ang);
+            }
+        }
+    } else if (wide) {
         const uint32_t lvl = __builtin_amdgcn_readfirstlane((uint32_t)((int)((float)(w * h) * f4.w) - w * h));
         const float2* plane = grad + lvl;
         const uint64_t pb = (uint64_t)plane;
@@ -1625,7 +1699,7 @@ struct mif_sift {
     hipEvent_t ev_feat[kOctaves][3] = {};    // feature phase: before detection, after emission, at the end
     int pyramid_frames = 0;                  // frames whose scale spaces await the feature phase
     int blur_launches = 0;                   // scale-space launches of the last enqueue_pyramid (all octaves)
-    bool desc_plain = false;                 // every descriptor window through the general loop (k_descriptor<true>)
+    int desc_mode = 2;                       // k_descriptor<MODE>: 0 general loop, 1 streamlined walk, 2 mark and visit
     // streams and events for running the octaves' feature kernels side by side (small inputs)
     hipStream_t aux[kOctaves] = {};          // [0] unused: octave 0 stays on `stream`
     hipEvent_t ev_fork = nullptr, ev_scan[kOctaves] = {}, ev_join[kOctaves] = {}, ev_l3[kOctaves] = {};
@@ -1915,14 +1989,13 @@ int enqueue_features(mif_sift* s, int want_desc)
                                    (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap, (const int*)s->counts,
                                    s->orient, s->ori_bins);
                 const dim3 dgrid(std::min(O.maxf, std::max(kDescBlocks, kDescBlocksTotal / nf)), nf);
-                if (s->desc_plain)
-                    hipLaunchKernelGGL(k_descriptor<true>, dgrid, dim3(128), 0, so, (const float4*)s->kp,
-                                       (const float*)s->orient, (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap,
-                                       (const int*)s->counts, s->desc);
-                else
-                    hipLaunchKernelGGL(k_descriptor<false>, dgrid, dim3(128), 0, so, (const float4*)s->kp,
-                                       (const float*)s->orient, (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap,
-                                       (const int*)s->counts, s->desc);
+#define MIF_LAUNCH_DESC(MODE)                                                                                     \
+    hipLaunchKernelGGL(k_descriptor<MODE>, dgrid, dim3(128), 0, so, (const float4*)s->kp, (const float*)s->orient, \
+                       (const float2*)O.grad, grad_stride, O.w, O.h, o, s->cap, (const int*)s->counts, s->desc)
+                if (s->desc_mode == 0) MIF_LAUNCH_DESC(0);
+                else if (s->desc_mode == 1) MIF_LAUNCH_DESC(1);
+                else MIF_LAUNCH_DESC(2);
+#undef MIF_LAUNCH_DESC
             }
         } else if (tm) {
             MIF_HIP(hipEventRecord(s->ev_feat[o][1], st));
@@ -2040,7 +2113,8 @@ int create_impl(mif_sift* s)
     build_ori_bins(&s->ori_bins);
     // a BGR pixel is fetched as a 32-bit word, which needs rows of at least four bytes
     if (const char* e = getenv("MIF_BLUR_PAIRS")) s->pair_mask = (unsigned)atoi(e) & 7u;      // A/B switch, 0 = one level per launch
-    if (const char* e = getenv("MIF_DESC_PLAIN")) s->desc_plain = atoi(e) != 0;               // A/B switch
+    if (const char* e = getenv("MIF_DESC_PLAIN")) s->desc_mode = atoi(e) != 0 ? 0 : s->desc_mode;   // A/B switches
+    if (const char* e = getenv("MIF_DESC_MODE")) s->desc_mode = std::max(0, std::min(2, atoi(e)));
     s->fused_base = s->fr[0] == kBaseRadius && s->oct[kOctaves - 1].w >= 2 && getenv("MIF_NO_FUSED_BASE") == nullptr;
     for (int o = 0; o < kOctaves; o++) {
         OctaveBuf& O = s->oct[o];

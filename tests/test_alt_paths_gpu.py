@@ -34,6 +34,16 @@ def test_unfused_paths_equal_the_default(tmp_path):
         assert a.tobytes() == b.tobytes(), k
 
 
+def test_descriptor_window_loops(tmp_path):
+    """The descriptor kernel has three window loops (general; streamlined walk; mark the pixels that pass the
+    cell test, then visit only those: the default): all must give the same bits. MIF_DESC_PLAIN=1 (general
+    loop) is part of test_unfused_paths_equal_the_default."""
+    ref = _run(tmp_path, "default", {})
+    alt = _run(tmp_path, "walk", {"MIF_DESC_MODE": "1"})
+    for k in ref.files:
+        assert ref[k].shape == alt[k].shape and ref[k].tobytes() == alt[k].tobytes(), k
+
+
 @pytest.mark.parametrize("mask", ["0", "7"])
 def test_scale_space_levels_singly_or_in_pairs(tmp_path, mask):
     """MIF_BLUR_PAIRS selects which levels of an octave are built two per launch (default: levels 0 and 1
