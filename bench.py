@@ -201,8 +201,28 @@ class Pipeline:
         self.h = [oda.SiftExtractor(width, height, channels, device=dev_index, batch=batch) for _ in range(2)]
         self.cap = self.h[0].capacity
         self.m = oda.Matcher(self.cap, self.cap, device=dev_index, max_pairs=batch)
-        self.h[1].set_stream(self.h[0].stream())
-        if os.environ.get("BENCH_MATCH_STREAM"):
+        self.split = int(os.environ.get("BENCH_CU_SPLIT", "0"))
+        self.masked = []
+        if self.split:
+            # experiment: the two handles on streams that own disjoint shares of the compute units
+            # (the low `split` of 256 mask bits and the rest), each with a matcher of its own
+            for lo, hi in ((0, self.split), (self.split, 256)):
+                words = (ctypes.c_uint32 * 8)(*[sum(1 << b for b in range(32) if lo <= 32 * wd + b < hi)
+                                                for wd in range(8)])
+                st = ctypes.c_void_p()
+                self._lib.check(self.lib.mif_stream_create_masked(dev_index, words, 8, ctypes.byref(st)))
+                self.masked.append(st.value)
+            if os.environ.get("BENCH_CU_SAME"):        # both handles on the first share: what a share can do alone
+                self.masked[1] = self.masked[0]
+            self.h[0].set_stream(self.masked[0])
+            self.h[1].set_stream(self.masked[1])
+            self.m2 = [self.m, oda.Matcher(self.cap, self.cap, device=dev_index, max_pairs=batch)]
+            self.serial = True
+        else:
+            self.h[1].set_stream(self.h[0].stream())
+        if self.split:
+            self.mstream = torch.cuda.ExternalStream(self.masked[0], device=self.dev)
+        elif os.environ.get("BENCH_MATCH_STREAM"):
             self.mstream = torch.cuda.Stream(device=self.dev)
         else:
             self.mstream = torch.cuda.ExternalStream(self.h[0].stream(), device=self.dev)
@@ -246,6 +266,12 @@ class Pipeline:
     def _match(self, k):
         if not self.match:
             return
+        if self.split:
+            st, other = self.masked[k % 2], self.masked[(k - 1) % 2]
+            self._wait(st, other)                  # the previous batch's last frame has been copied aside
+            self.m2[k % 2].top2_batch_device(self._pairs(k), self.cap, self.cap, 127, 128, self._lib.FILTER_SIFT,
+                                             stream=st)
+            return
         self.m.top2_batch_device(self._pairs(k), self.cap, self.cap, 127, 128, self._lib.FILTER_SIFT,
                                  stream=self.mstream.cuda_stream)
 
@@ -253,8 +279,9 @@ class Pipeline:
         k = self.step_no
         h, other, ms = self.h[k % 2], self.h[(k - 1) % 2], self.mstream.cuda_stream
         # (waits between equal streams return at once: stream order already holds)
-        self._wait(h.stream(), other.stream())     # extraction runs batch after batch
-        self._wait(h.stream(), ms)                 # the matcher two batches back read this handle's results
+        if not self.split:
+            self._wait(h.stream(), other.stream())     # extraction runs batch after batch
+            self._wait(h.stream(), ms)                 # the matcher two batches back read this handle's results
         h.enqueue_pyramid(frames_ptr, self.B)
         if self.pending and not self.serial:
             self._wait(ms, h.stream())             # after the scale spaces
@@ -270,7 +297,8 @@ class Pipeline:
         """Matches the batch extracted last, if that has not happened yet."""
         if self.pending:
             k = self.step_no - 1
-            self._wait(self.mstream.cuda_stream, self.h[k % 2].stream())
+            if not self.split:
+                self._wait(self.mstream.cuda_stream, self.h[k % 2].stream())
             self._match(k)
             self.pending = False
 

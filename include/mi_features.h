@@ -110,6 +110,14 @@ int mif_sift_snapshot_frame(mif_sift* s, int frame, float* d_descriptors, int32_
  * chains tasks with add_dependence (clDriver.h); streams are HIP stream handles (mif_sift_stream). */
 int mif_stream_wait_stream(int device, void* waiter, void* signaller);
 
+/* A stream whose kernels run only on the compute units whose bit is set in cu_mask (words x 32 bits,
+ * bit i = compute unit i in the driver's numbering, which deals consecutive bits to the device's XCDs in
+ * turn: the low n bits are n / 8 compute units of every XCD). Two streams with disjoint masks run their
+ * kernels side by side, each on its share of the device. No counterpart in the reference (its two devices
+ * are a CPU and a GPU, clDriver.h:1311-1432). mif_stream_destroy waits for the stream's work first. */
+int mif_stream_create_masked(int device, const uint32_t* cu_mask, int words, void** stream);
+int mif_stream_destroy(int device, void* stream);
+
 /* Blocks until everything enqueued on the handle has finished. */
 int mif_sift_sync(mif_sift* s);
 /* Makes everything enqueued on s from now on wait for what has been enqueued

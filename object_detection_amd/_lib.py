@@ -32,6 +32,8 @@ SYMBOLS = [
     ("mif_sift_enqueue_features", C.c_int, [_P, C.c_int]),
     ("mif_sift_snapshot_frame", C.c_int, [_P, C.c_int, _P, _P]),
     ("mif_stream_wait_stream", C.c_int, [C.c_int, _P, _P]),
+    ("mif_stream_create_masked", C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(_P)]),
+    ("mif_stream_destroy", C.c_int, [C.c_int, _P]),
     ("mif_sift_wait_for", C.c_int, [_P, _P]),
     ("mif_sift_copy_results", C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int, _PI]),
     ("mif_sift_sync", C.c_int, [_P]),

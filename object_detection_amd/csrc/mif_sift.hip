@@ -2276,6 +2276,29 @@ int mif_stream_wait_stream(int device, void* waiter, void* signaller)
     return MIF_OK;
 }
 
+int mif_stream_create_masked(int device, const uint32_t* cu_mask, int words, void** stream)
+{
+    if (!cu_mask || words < 1 || !stream) {
+        mif::set_error("mif_stream_create_masked: bad argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(device);
+    if (!guard.ok) { mif::set_error("mif_stream_create_masked: cannot select device %d", device); return MIF_ERR_HIP; }
+    hipStream_t st = nullptr;
+    MIF_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, cu_mask));
+    *stream = st;
+    return MIF_OK;
+}
+
+int mif_stream_destroy(int device, void* stream)
+{
+    if (!stream) return MIF_OK;
+    mif::DeviceGuard guard(device);
+    MIF_HIP(hipStreamSynchronize((hipStream_t)stream));
+    MIF_HIP(hipStreamDestroy((hipStream_t)stream));
+    return MIF_OK;
+}
+
 int mif_sift_set_stream(mif_sift* s, void* stream)
 {
     if (!s) { mif::set_error("mif_sift_set_stream: NULL handle"); return MIF_ERR_INVALID_ARGUMENT; }

@@ -218,3 +218,36 @@ def test_odd_sized_batches_against_checker(geom):
         assert np.array_equal(feat.keypoints.view(np.uint32), kp.view(np.uint32)), f
         assert np.array_equal(feat.orientations.view(np.uint32), ori.view(np.uint32)), f
         assert np.array_equal(feat.descriptors.view(np.uint32), des.view(np.uint32)), f
+
+
+def test_extraction_on_a_stream_with_a_share_of_the_compute_units():
+    """mif_stream_create_masked: a handle enqueued on a stream that owns the low 64 of 256 compute units
+    returns the bits of a handle on its own stream (the kernels' grids do not depend on where they run)."""
+    import ctypes as C
+    import torch
+    frames = _frames()
+    B = len(frames)
+    px = torch.from_numpy(np.stack(frames)).to(torch.device("cuda:0"))
+    lib = oda.load_library()
+    mask = (C.c_uint32 * 8)(0xFFFFFFFF, 0xFFFFFFFF, 0, 0, 0, 0, 0, 0)
+    st = C.c_void_p()
+    _lib.check(lib.mif_stream_create_masked(0, mask, 8, C.byref(st)))
+    try:
+        one = oda.SiftExtractor(256, 192, 1, batch=B)
+        one.enqueue(px.data_ptr(), B)
+        two = oda.SiftExtractor(256, 192, 1, batch=B)
+        two.set_stream(st.value)
+        two.enqueue(px.data_ptr(), B)
+        total = 0
+        for f in range(B):
+            rc1, a = one.copy_results(f)
+            rc2, b = two.copy_results(f)
+            assert rc1 == rc2 and a.counts == b.counts
+            assert np.array_equal(a.keypoints.view(np.uint32), b.keypoints.view(np.uint32))
+            assert np.array_equal(a.descriptors.view(np.uint32), b.descriptors.view(np.uint32))
+            total += sum(a.counts)
+        assert total > 100
+        two.set_stream(None)
+    finally:
+        _lib.check(lib.mif_stream_destroy(0, st))
+    assert lib.mif_stream_create_masked(0, None, 8, C.byref(st)) != 0
