@@ -201,12 +201,13 @@ class Pipeline:
         self.h = [oda.SiftExtractor(width, height, channels, device=dev_index, batch=batch) for _ in range(2)]
         self.cap = self.h[0].capacity
         self.m = oda.Matcher(self.cap, self.cap, device=dev_index, max_pairs=batch)
-        self.split = int(os.environ.get("BENCH_CU_SPLIT", "0"))
+        self.split = int(os.environ.get("BENCH_CU_SPLIT", "256" if os.environ.get("BENCH_TWO_STREAMS") else "0"))
         self.masked = []
         if self.split:
             # experiment: the two handles on streams that own disjoint shares of the compute units
-            # (the low `split` of 256 mask bits and the rest), each with a matcher of its own
-            for lo, hi in ((0, self.split), (self.split, 256)):
+            # (the low `split` of 256 mask bits and the rest; 256 = BENCH_TWO_STREAMS: both streams own the
+            # whole device and run their batches side by side), each with a matcher of its own
+            for lo, hi in ((0, self.split), (self.split, 256)) if self.split < 256 else ((0, 256), (0, 256)):
                 words = (ctypes.c_uint32 * 8)(*[sum(1 << b for b in range(32) if lo <= 32 * wd + b < hi)
                                                 for wd in range(8)])
                 st = ctypes.c_void_p()
