@@ -700,6 +700,35 @@ __device__ __forceinline__ float max_raw(float a, float b)
 // WV waves per block: 4 (256 queries per work item; two blocks per compute unit) for batches of small
 // searches, 8 (512 queries, one block per compute unit) for large ones, where every staged database row
 // then serves twice the queries and the blocks ask half as much of the L2.
+// Between the two passes of k_match_screen2 / k_match_screen4: per (pair, query) the limit of pass 1
+// from the bounds pass 0 left per split, written over the bound of split 0. A work item of pass 1
+// (one per split and query tile) then reads one value per query instead of walking all splits: with 64
+// splits that walk, a chain of dependent loads at the head of every item, took a quarter of the pass.
+// A row is kept when a >= (|q|^2 - (t + 2 m)) / 2, t the smallest of the splits' bounds (as scores):
+// +inf while no split holds two rows, so that every row is kept. grid (ceil(nq_cap / 256), pairs).
+__global__ __launch_bounds__(256) void k_match_limits(PairTable tbl, int nq_cap, int nd_cap,
+                                                      const float* __restrict__ qn_all,
+                                                      const unsigned int* __restrict__ dnmax_all, int nsplit,
+                                                      float* __restrict__ t2_all)
+{
+    const int z = blockIdx.y;
+    const mif_match_pair& pz = tbl[z];
+    const int nq = pz.d_nq ? min(*pz.d_nq, nq_cap) : nq_cap;
+    const int nd = pz.d_nd ? min(*pz.d_nd, nd_cap) : nd_cap;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const int chunks = (nd + kDC - 1) / kDC;
+    const int per = (chunks + nsplit - 1) / nsplit;
+    float* __restrict__ t2s = t2_all + (size_t)z * nsplit * nq_cap;
+    float t = kInf;
+    for (int sp = 0; sp * per < chunks; sp++) t = fminf(t, t2s[(size_t)sp * nq_cap + i]);
+    const float qnv = qn_all[(size_t)z * nq_cap + i];
+    const float dmax = __builtin_bit_cast(float, dnmax_all[z]);
+    const float m = kScreenRel * __builtin_sqrtf(qnv * dmax) + 3.0f * kScreenAbs * (qnv + dmax);
+    const float limit = t + 2.0f * m;
+    t2s[i] = 0.5f * (qnv - limit);
+}
+
 template <int K, bool VEC, int PASS, int WV>
 __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl, int npairs, int nq_cap, int nd_cap, int dim,
                                                        int ld, const float* __restrict__ qn_all,
@@ -885,18 +914,10 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
     // smallest of any one split, so the smallest of the splits' values (+ 2 m) keeps every winner.
     float alim[2] = {kInf, kInf};
     int filled[2] = {0, 0};
-    if (PASS == 1) {
+    if (PASS == 1) {            // (k_match_limits left the query's limit in the slot of split 0)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-            if (qi[s2] < nq) {
-                float t = kInf;
-                for (int sp = 0; sp * per < chunks; sp++) t = fminf(t, t2s[(size_t)sp * nq_cap + qi[s2]]);
-                const float dmax = __builtin_bit_cast(float, dnmax_all[z]);
-                const float m = kScreenRel * __builtin_sqrtf(qnv[s2] * dmax) + 3.0f * kScreenAbs * (qnv[s2] + dmax);
-                const float limit = t + 2.0f * m;       // +inf while no split holds two rows: every row is kept
-                alim[s2] = 0.5f * (qnv[s2] - limit);
-            }
-        }
+        for (int s2 = 0; s2 < 2; s2++)
+            if (qi[s2] < nq) alim[s2] = t2s[qi[s2]];
     }
 
     auto consider = [&](const f32x16& acc, int jbase, int s2, bool full) {
@@ -1219,18 +1240,10 @@ __global__ __launch_bounds__(512, 1) void k_match_screen4(PairTable tbl, int npa
     // smallest of any one split, so the smallest of the splits' values (+ 2 m) keeps every winner.
     float alim[2] = {kInf, kInf};
     int filled[2] = {0, 0};
-    if (PASS == 1) {
+    if (PASS == 1) {            // (k_match_limits left the query's limit in the slot of split 0)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; s2++) {
-            if (qi[s2] < nq) {
-                float t = kInf;
-                for (int sp = 0; sp * per < chunks; sp++) t = fminf(t, t2s[(size_t)sp * nq_cap + qi[s2]]);
-                const float dmax = __builtin_bit_cast(float, dnmax_all[z]);
-                const float m = kScreenRel * __builtin_sqrtf(qnv[s2] * dmax) + 3.0f * kScreenAbs * (qnv[s2] + dmax);
-                const float limit = t + 2.0f * m;       // +inf while no split holds two rows: every row is kept
-                alim[s2] = 0.5f * (qnv[s2] - limit);
-            }
-        }
+        for (int s2 = 0; s2 < 2; s2++)
+            if (qi[s2] < nq) alim[s2] = t2s[qi[s2]];
     }
 
     auto consider = [&](const f32x16& acc, int jbase, int s2, bool full) {
@@ -1369,6 +1382,13 @@ __global__ __launch_bounds__(128) void k_match_rank(PairTable tbl, int nq_cap, i
     const int per = (chunks + nsplit - 1) / nsplit;
     Top2 t;
     const float* q = Q + (size_t)i * ld;
+    // the query's row stays in registers (dim <= 128): every candidate row is met by the same values
+    float vq[4][32];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const int k0 = 32 * b;
+        if (k0 < dim) load_span<VEC>(q + k0, min(32, ld - k0), vq[b]);
+    }
     // The lists of the query's splits; a list that overflowed stands for all rows of its split. If the
     // lists hold fewer rows than the answer has (scores that are not numbers compare false), they are
     // not trusted and a second round takes every row. One copy of the row loop serves all cases.
@@ -1389,15 +1409,17 @@ __global__ __launch_bounds__(128) void k_match_rank(PairTable tbl, int nq_cap, i
                 const int j = all ? lo + c : list[c];
                 const float* r = D + (size_t)j * ld;
                 float acc = 0.0f;
-                for (int k0 = 0; k0 < dim; k0 += 32) {
-                    const int span = min(32, dim - k0);
-                    const int avail = min(32, ld - k0);
-                    float vq[32], vd[32];
-                    load_span<VEC>(q + k0, avail, vq);
-                    load_span<VEC>(r + k0, avail, vd);
 #pragma unroll
-                    for (int k = 0; k < 32; k++)
-                        if (k < span) acc = __builtin_fmaf(vd[k], vq[k], acc);
+                for (int b = 0; b < 4; b++) {
+                    const int k0 = 32 * b;
+                    if (k0 < dim) {
+                        const int span = min(32, dim - k0);
+                        float vd[32];
+                        load_span<VEC>(r + k0, min(32, ld - k0), vd);
+#pragma unroll
+                        for (int k = 0; k < 32; k++)
+                            if (k < span) acc = __builtin_fmaf(vd[k], vq[b][k], acc);
+                    }
                 }
                 top2_insert(t, __builtin_fmaf(-2.0f, acc, qnv + dn[j]), j);
             }
@@ -1743,14 +1765,21 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
                                nq, nd, dim, ld, (const float*)qn, (const float*)dn, (const unsigned int*)nmax,   \
                                nsplit, thr, ccnt, cand, m->work + 1 + PASS);                                     \
     } while (0)
+#define MIF_LAUNCH_LIMITS()                                                                                      \
+    do {                                                                                                         \
+        if (!screen_v1)                                                                                          \
+            hipLaunchKernelGGL(k_match_limits, dim3((nq + 255) / 256, np), dim3(256), 0, st, tbl, nq, nd,        \
+                               (const float*)qn, (const unsigned int*)nmax, nsplit, thr);                        \
+    } while (0)
                 if (dim <= 64) {
-                    if (vec) { MIF_LAUNCH_SCREEN(64, true, 0); MIF_LAUNCH_SCREEN(64, true, 1); }
-                    else     { MIF_LAUNCH_SCREEN(64, false, 0); MIF_LAUNCH_SCREEN(64, false, 1); }
+                    if (vec) { MIF_LAUNCH_SCREEN(64, true, 0); MIF_LAUNCH_LIMITS(); MIF_LAUNCH_SCREEN(64, true, 1); }
+                    else     { MIF_LAUNCH_SCREEN(64, false, 0); MIF_LAUNCH_LIMITS(); MIF_LAUNCH_SCREEN(64, false, 1); }
                 } else {
-                    if (vec) { MIF_LAUNCH_SCREEN(128, true, 0); MIF_LAUNCH_SCREEN(128, true, 1); }
-                    else     { MIF_LAUNCH_SCREEN(128, false, 0); MIF_LAUNCH_SCREEN(128, false, 1); }
+                    if (vec) { MIF_LAUNCH_SCREEN(128, true, 0); MIF_LAUNCH_LIMITS(); MIF_LAUNCH_SCREEN(128, true, 1); }
+                    else     { MIF_LAUNCH_SCREEN(128, false, 0); MIF_LAUNCH_LIMITS(); MIF_LAUNCH_SCREEN(128, false, 1); }
                 }
 #undef MIF_LAUNCH_SCREEN
+#undef MIF_LAUNCH_LIMITS
                 if (vec)
                     hipLaunchKernelGGL(k_match_rank<true>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim,
                                        ld, (const float*)qn, (const float*)dn, nsplit, (const int*)ccnt, (const int*)cand, ps, pi,
