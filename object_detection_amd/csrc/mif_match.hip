@@ -704,12 +704,13 @@ __device__ __forceinline__ float max_raw(float a, float b)
 // from the bounds pass 0 left per split, written over the bound of split 0. A work item of pass 1
 // (one per split and query tile) then reads one value per query instead of walking all splits: with 64
 // splits that walk, a chain of dependent loads at the head of every item, took a quarter of the pass.
-// A row is kept when a >= (|q|^2 - (t + 2 m)) / 2, t the smallest of the splits' bounds (as scores):
-// +inf while no split holds two rows, so that every row is kept. grid (ceil(nq_cap / 256), pairs).
+// A row is kept when a >= (|q|^2 - (t + 2 m)) / 2, t a bound on the second smallest score (below):
+// +inf while the database holds fewer than two rows, so that every row is kept.
+// grid (ceil(nq_cap / 256), pairs).
 __global__ __launch_bounds__(256) void k_match_limits(PairTable tbl, int nq_cap, int nd_cap,
                                                       const float* __restrict__ qn_all,
                                                       const unsigned int* __restrict__ dnmax_all, int nsplit,
-                                                      float* __restrict__ t2_all)
+                                                      float* __restrict__ t2_all, size_t s1_off)
 {
     const int z = blockIdx.y;
     const mif_match_pair& pz = tbl[z];
@@ -720,8 +721,16 @@ __global__ __launch_bounds__(256) void k_match_limits(PairTable tbl, int nq_cap,
     const int chunks = (nd + kDC - 1) / kDC;
     const int per = (chunks + nsplit - 1) / nsplit;
     float* __restrict__ t2s = t2_all + (size_t)z * nsplit * nq_cap;
-    float t = kInf;
-    for (int sp = 0; sp * per < chunks; sp++) t = fminf(t, t2s[(size_t)sp * nq_cap + i]);
+    // the second smallest score over all rows is at most the bound any split found for its own second
+    // smallest, and at most the second smallest of the splits' smallest scores (two different rows)
+    float t = kInf, b1 = kInf, b2 = kInf;
+    for (int sp = 0; sp * per < chunks; sp++) {
+        t = fminf(t, t2s[(size_t)sp * nq_cap + i]);
+        const float v = t2s[s1_off + (size_t)sp * nq_cap + i];
+        b2 = fminf(b2, fmaxf(b1, v));
+        b1 = fminf(b1, v);
+    }
+    t = fminf(t, b2);
     const float qnv = qn_all[(size_t)z * nq_cap + i];
     const float dmax = __builtin_bit_cast(float, dnmax_all[z]);
     const float m = kScreenRel * __builtin_sqrtf(qnv * dmax) + 3.0f * kScreenAbs * (qnv + dmax);
@@ -734,8 +743,8 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
                                                        int ld, const float* __restrict__ qn_all,
                                                        const float* __restrict__ dn_all,
                                                        const unsigned int* __restrict__ dnmax_all, int nsplit,
-                                                       float* __restrict__ t2_all, int* __restrict__ cnt_all,
-                                                       int* __restrict__ cand_all,
+                                                       float* __restrict__ t2_all, size_t s1_off,
+                                                       int* __restrict__ cnt_all, int* __restrict__ cand_all,
                                                        unsigned int* __restrict__ work_counter)
 {
     constexpr int KP = K + 16;                 // contraction length with the norm's k-step
@@ -1001,8 +1010,11 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
             float a1 = t1[s2], a2 = t2[s2];
             a2 = __builtin_amdgcn_fmed3f(a1, a2, o1); a1 = fmaxf(a1, o1);
             a2 = __builtin_amdgcn_fmed3f(a1, a2, o2); a1 = fmaxf(a1, o2);
-            // as a score; +inf when the split holds fewer than two rows (a2 = -inf or a padded row's -3e38)
-            if (half == 0 && qi[s2] < nq) t2s[(size_t)split * nq_cap + qi[s2]] = __builtin_fmaf(-2.0f, a2, qnv[s2]);
+            // as scores; +inf when the split holds fewer rows (-inf or a padded row's -3e38)
+            if (half == 0 && qi[s2] < nq) {
+                t2s[(size_t)split * nq_cap + qi[s2]] = __builtin_fmaf(-2.0f, a2, qnv[s2]);
+                t2s[s1_off + (size_t)split * nq_cap + qi[s2]] = __builtin_fmaf(-2.0f, a1, qnv[s2]);
+            }
         } else if (half == 0 && qi[s2] < nq) {
             cnt[qi[s2]] = filled[s2];
         }
@@ -1094,8 +1106,8 @@ __global__ __launch_bounds__(512, 1) void k_match_screen4(PairTable tbl, int npa
                                                           int ld, const float* __restrict__ qn_all,
                                                           const __bf16* __restrict__ dbf_all, int rows_pad,
                                                           const unsigned int* __restrict__ dnmax_all, int nsplit,
-                                                          float* __restrict__ t2_all, int* __restrict__ cnt_all,
-                                                          int* __restrict__ cand_all,
+                                                          float* __restrict__ t2_all, size_t s1_off,
+                                                          int* __restrict__ cnt_all, int* __restrict__ cand_all,
                                                           unsigned int* __restrict__ work_counter)
 {
     constexpr int KP = K + 16;                 // contraction length with the norm's k-step
@@ -1346,10 +1358,18 @@ __global__ __launch_bounds__(512, 1) void k_match_screen4(PairTable tbl, int npa
     for (int s2 = 0; s2 < 2; s2++) {
         if (PASS == 0) {
             // lanes l and l + 32 hold the same query (interleaved database rows)
-            const float a1 = fmaxf(t1[s2], __shfl_xor(t1[s2], 32));
-            const float a2 = fminf(a1, fmaxf(t2[s2], __shfl_xor(t2[s2], 32)));
-            // as a score; +inf when a tile class holds no row (a2 = -inf or a padded row's -3e38)
-            if (half == 0 && qi[s2] < nq) t2s[(size_t)split * nq_cap + qi[s2]] = __builtin_fmaf(-2.0f, a2, qnv[s2]);
+            // four disjoint classes of rows (this lane's or the other's, even or odd tiles): the largest
+            // of their maxima is the split's largest result and the second largest of them a bound on
+            // its second largest
+            const float e0 = t1[s2], o0 = t2[s2], e1 = __shfl_xor(t1[s2], 32), o1 = __shfl_xor(t2[s2], 32);
+            const float ea = fmaxf(e0, e1), eb = fminf(e0, e1), oa = fmaxf(o0, o1), ob = fminf(o0, o1);
+            const float a1 = fmaxf(ea, oa);
+            const float a2 = fmaxf(fminf(ea, oa), fmaxf(eb, ob));
+            // as scores; +inf for a class without rows (-inf or a padded row's -3e38)
+            if (half == 0 && qi[s2] < nq) {
+                t2s[(size_t)split * nq_cap + qi[s2]] = __builtin_fmaf(-2.0f, a2, qnv[s2]);
+                t2s[s1_off + (size_t)split * nq_cap + qi[s2]] = __builtin_fmaf(-2.0f, a1, qnv[s2]);
+            }
         } else if (half == 0 && qi[s2] < nq) {
             cnt[qi[s2]] = filled[s2];
         }
@@ -1754,22 +1774,23 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
                                    dim3(256), 0, st, tbl, nd, m->rows_pad, dim, ld, (const float*)dn, dbf);      \
             hipLaunchKernelGGL((k_match_screen4<KK, V, PASS>), dim3(m->blocks / 2), dim3(512), 0, st, tbl, np,  \
                                nq, nd, dim, ld, (const float*)qn, (const __bf16*)dbf, m->rows_pad,              \
-                               (const unsigned int*)nmax, nsplit, thr, ccnt, cand, m->work + 1 + PASS);          \
+                               (const unsigned int*)nmax, nsplit, thr, m->screen_slots, ccnt, cand,             \
+                               m->work + 1 + PASS);                                                              \
         }                                                                                                        \
         else if (wide)                                                                                           \
             hipLaunchKernelGGL((k_match_screen2<KK, V, PASS, 8>), dim3(m->blocks / 2), dim3(512), 0, st, tbl, np,  \
                                nq, nd, dim, ld, (const float*)qn, (const float*)dn, (const unsigned int*)nmax,   \
-                               nsplit, thr, ccnt, cand, m->work + 1 + PASS);                                     \
+                               nsplit, thr, m->screen_slots, ccnt, cand, m->work + 1 + PASS);                    \
         else                                                                                                     \
             hipLaunchKernelGGL((k_match_screen2<KK, V, PASS, 4>), dim3(m->blocks), dim3(256), 0, st, tbl, np,    \
                                nq, nd, dim, ld, (const float*)qn, (const float*)dn, (const unsigned int*)nmax,   \
-                               nsplit, thr, ccnt, cand, m->work + 1 + PASS);                                     \
+                               nsplit, thr, m->screen_slots, ccnt, cand, m->work + 1 + PASS);                    \
     } while (0)
 #define MIF_LAUNCH_LIMITS()                                                                                      \
     do {                                                                                                         \
         if (!screen_v1)                                                                                          \
             hipLaunchKernelGGL(k_match_limits, dim3((nq + 255) / 256, np), dim3(256), 0, st, tbl, nq, nd,        \
-                               (const float*)qn, (const unsigned int*)nmax, nsplit, thr);                        \
+                               (const float*)qn, (const unsigned int*)nmax, nsplit, thr, m->screen_slots);       \
     } while (0)
                 if (dim <= 64) {
                     if (vec) { MIF_LAUNCH_SCREEN(64, true, 0); MIF_LAUNCH_LIMITS(); MIF_LAUNCH_SCREEN(64, true, 1); }
@@ -1965,7 +1986,8 @@ int mif_match_create_batched(int device, int max_query, int max_database, int ma
     // room for a batch without database splits or for one pair with every split
     m->screen_slots = std::max<size_t>(P, kMaxSplit) * (size_t)max_query;
     if ((e = hipMalloc(&m->dnmax, P * sizeof(unsigned int))) != hipSuccess) return fail(e);
-    if ((e = hipMalloc(&m->thr, m->screen_slots * sizeof(float))) != hipSuccess) return fail(e);
+    // two values per (pair, split, query): the bound on the second smallest score, then the smallest score
+    if ((e = hipMalloc(&m->thr, 2 * m->screen_slots * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->cand_cnt, m->screen_slots * sizeof(int))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->cand, m->screen_slots * kCandCap * sizeof(int))) != hipSuccess) return fail(e);
     // the bf16 image of the database rows for the screening passes of large searches (kTurnsMinScores);
