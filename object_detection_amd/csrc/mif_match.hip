@@ -1624,9 +1624,10 @@ constexpr int kMaxSplit = 64;
 constexpr double kScreenMinScores = 3.2e7;
 constexpr int kScreenSplitRows = 32768;     // most rows of a database split under screening
 // The screening passes through the bf16 image (k_match_pack_rows, k_match_screen4) pay for the image and for
-// their long start of a work item only on large searches: measured against k_match_screen2 they lose up to
-// 65536 x 65536 rows, draw at 65536 x 262144 and win 10 % at 1 M x 1 M. Row counts known on the host only.
-constexpr double kTurnsMinScores = 1.5e10;
+// their long start of a work item only on large searches: measured against k_match_screen2 they lose at
+// 8192 x 8192 rows and below, draw at 16384 x 65536 and win 9-17 % from 65536 x 65536 to 1 M x 1 M. Row counts
+// known on the host only.
+constexpr double kTurnsMinScores = 2e9;
 constexpr int kTurnsMinQueries = 16384;
 constexpr int kTurnsMinRows = 65536;
 
