@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(512, 1) void k_match_screen4(PairTable tbl, int npa
                                                           const unsigned int* __restrict__ dnmax_all, int nsplit,
                                                           float* __restrict__ t2_all, size_t s1_off,
                                                           int* __restrict__ cnt_all, int* __restrict__ cand_all,
-                                                          unsigned int* __restrict__ work_counter)
+                                                          unsigned int* __restrict__ work_counter, int sample)
 {
     constexpr int KP = K + 16;                 // contraction length with the norm's k-step
     constexpr int KS = KP / 16;                // matrix instructions per tile
@@ -1336,16 +1336,21 @@ __global__ __launch_bounds__(512, 1) void k_match_screen4(PairTable tbl, int npa
     // chunk c_lo has to be in LDS before the first matrix phase
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int c = c_lo; c < c_hi; c++) {
-        const int buf = (c - c_lo) & 1;
+    // pass 0 may look at every `sample`-th chunk only: the bounds it leaves then hold for a subset of the
+    // rows, and the second smallest score of a subset is at least that of all rows (a looser, still
+    // valid limit for pass 1, for an n-th of the matrix work)
+    const int cs = PASS == 0 ? sample : 1;
+    const int c_last = c_lo + (c_hi - 1 - c_lo) / cs * cs;
+    int buf = 0;
+    for (int c = c_lo; c < c_hi; c += cs, buf ^= 1) {
         // The next chunk is fetched by the half that is in its (shorter) vector phase: issuing a copy
         // costs a wave 60-180 cycles, which the matrix phase cannot spare. Its buffer was last read in
         // half period 2c - 1.
         if (group == 0) {
             matrix_phase(buf);
         } else {
-            if (c + 1 < c_hi) copy_chunk(c + 1, buf ^ 1, wave - 4, 4);
-            if (c > c_lo) vector_phase(c - 1);
+            if (c + cs < c_hi) copy_chunk(c + cs, buf ^ 1, wave - 4, 4);
+            if (c > c_lo) vector_phase(c - cs);
         }
         __builtin_amdgcn_s_barrier();
         if (group == 0) vector_phase(c);
@@ -1353,7 +1358,7 @@ __global__ __launch_bounds__(512, 1) void k_match_screen4(PairTable tbl, int npa
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the pieces of chunk c + 1 this wave issued have landed
         __builtin_amdgcn_s_barrier();
     }
-    if (group == 1) vector_phase(c_hi - 1);
+    if (group == 1) vector_phase(c_last);
 #pragma unroll
     for (int s2 = 0; s2 < 2; s2++) {
         if (PASS == 0) {
@@ -1378,8 +1383,19 @@ __global__ __launch_bounds__(512, 1) void k_match_screen4(PairTable tbl, int npa
   }
 }
 
+// A query whose candidate lists do not settle its answer: the splits whose rows all have to be ranked
+// (bit sp of `splits`), for k_match_overflow.
+struct OverflowEntry {
+    int pair, query;
+    unsigned long long splits;
+};
+
 // Ranks the candidates of the screening passes with the exact search's arithmetic and writes the
-// two winners where k_match_partial would have written them (split 0), for k_match_finalize.
+// two winners where k_match_finalize reads them (slot 0 of the query; slot 1 is for k_match_overflow
+// and starts empty). A list that overflowed stands for all rows of its split, and lists that hold fewer
+// rows than the answer has (scores that are not numbers compare false) are not trusted at all: such
+// queries go to the overflow queue (one entry per query at most, so the queue of pairs * nq_cap
+// entries cannot fill) and a block of k_match_overflow ranks the rows of those splits.
 // grid (ceil(nq_cap/128), npairs), one thread per query.
 template <bool VEC>
 __global__ __launch_bounds__(128) void k_match_rank(PairTable tbl, int nq_cap, int nd_cap, int dim, int ld,
@@ -1387,7 +1403,7 @@ __global__ __launch_bounds__(128) void k_match_rank(PairTable tbl, int nq_cap, i
                                                     int nsplit, const int* __restrict__ cnt_all,
                                                     const int* __restrict__ cand_all,
                                                     float* __restrict__ part_s_all, int* __restrict__ part_i_all,
-                                                    int part_stride)
+                                                    OverflowEntry* __restrict__ queue, unsigned int* __restrict__ queue_count)
 {
     const mif_match_pair& pr = tbl[blockIdx.y];
     const int nq = pr.d_nq ? min(*pr.d_nq, nq_cap) : nq_cap;
@@ -1401,6 +1417,8 @@ __global__ __launch_bounds__(128) void k_match_rank(PairTable tbl, int nq_cap, i
     const int chunks = (nd + kDC - 1) / kDC;
     const int per = (chunks + nsplit - 1) / nsplit;
     Top2 t;
+    t.s1 = t.s2 = kInf;
+    t.i1 = t.i2 = 0x7fffffff;
     const float* q = Q + (size_t)i * ld;
     // the query's row stays in registers (dim <= 128): every candidate row is met by the same values
     float vq[4][32];
@@ -1409,24 +1427,96 @@ __global__ __launch_bounds__(128) void k_match_rank(PairTable tbl, int nq_cap, i
         const int k0 = 32 * b;
         if (k0 < dim) load_span<VEC>(q + k0, min(32, ld - k0), vq[b]);
     }
-    // The lists of the query's splits; a list that overflowed stands for all rows of its split. If the
-    // lists hold fewer rows than the answer has (scores that are not numbers compare false), they are
-    // not trusted and a second round takes every row. One copy of the row loop serves all cases.
-    bool every_row = false;
-    for (;;) {
+    int listed = 0;
+    unsigned long long deferred = 0ull, with_rows = 0ull;
+    for (int sp = 0; sp * per < chunks; sp++) {
+        const size_t at = ((size_t)blockIdx.y * nsplit + sp) * nq_cap + i;
+        const int n = cnt_all[at];
+        listed += n;
+        with_rows |= 1ull << sp;
+        if (n > kCandCap) {
+            deferred |= 1ull << sp;
+            continue;
+        }
+        const int* __restrict__ list = cand_all + at * kCandCap;
+        for (int c = 0; c < n; c++) {
+            const int j = list[c];
+            const float* r = D + (size_t)j * ld;
+            float acc = 0.0f;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int k0 = 32 * b;
+                if (k0 < dim) {
+                    const int span = min(32, dim - k0);
+                    float vd[32];
+                    load_span<VEC>(r + k0, min(32, ld - k0), vd);
+#pragma unroll
+                    for (int k = 0; k < 32; k++)
+                        if (k < span) acc = __builtin_fmaf(vd[k], vq[b][k], acc);
+                }
+            }
+            top2_insert(t, __builtin_fmaf(-2.0f, acc, qnv + dn[j]), j);
+        }
+    }
+    if (listed < min(2, nd)) {          // the lists cannot hold the answer: every row is ranked
+        deferred = with_rows;
         t.s1 = t.s2 = kInf;
         t.i1 = t.i2 = 0x7fffffff;
-        int listed = 0;
-        for (int sp = 0; sp * per < chunks; sp++) {
-            const size_t at = ((size_t)blockIdx.y * nsplit + sp) * nq_cap + i;
-            const int n = every_row ? kCandCap + 1 : cnt_all[at];
-            listed += n;
-            const bool all = n > kCandCap;
+    }
+    if (deferred != 0ull) {
+        const unsigned int e = atomicAdd(queue_count, 1u);
+        queue[e].pair = blockIdx.y;
+        queue[e].query = i;
+        queue[e].splits = deferred;
+    }
+    // slots [pair][2][nq_cap][2]
+    const size_t o = ((size_t)blockIdx.y * 2 * nq_cap + i) * 2;
+    part_s_all[o] = t.s1; part_s_all[o + 1] = t.s2;
+    part_i_all[o] = t.i1; part_i_all[o + 1] = t.i2;
+    const size_t o1 = o + (size_t)nq_cap * 2;
+    part_s_all[o1] = kInf; part_s_all[o1 + 1] = kInf;
+    part_i_all[o1] = 0x7fffffff; part_i_all[o1 + 1] = 0x7fffffff;
+}
+
+// The queries k_match_rank queued: a block per entry (persistent blocks stride over the queue) ranks all
+// rows of the entry's splits, a row per thread and step, and leaves the two winners in slot 1 of the
+// query. The order in which rows meet does not matter: winners are chosen on (score, index).
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_match_overflow(PairTable tbl, int nq_cap, int nd_cap, int dim, int ld,
+                                                        const float* __restrict__ qn_all, const float* __restrict__ dn_all,
+                                                        int nsplit, const OverflowEntry* __restrict__ queue,
+                                                        const unsigned int* __restrict__ queue_count,
+                                                        float* __restrict__ part_s_all, int* __restrict__ part_i_all)
+{
+    __shared__ Top2 s_top[256];
+    const unsigned int n_entries = *queue_count;
+    const int tid = threadIdx.x;
+    for (unsigned int e = blockIdx.x; e < n_entries; e += gridDim.x) {      // uniform over the block
+        const OverflowEntry en = queue[e];
+        const mif_match_pair& pr = tbl[en.pair];
+        const int nd = pr.d_nd ? min(*pr.d_nd, nd_cap) : nd_cap;
+        const float* __restrict__ D = pr.d_db;
+        const float* q = pr.d_q + (size_t)en.query * ld;
+        const float qnv = qn_all[(size_t)en.pair * nq_cap + en.query];
+        const float* __restrict__ dn = dn_all + (size_t)en.pair * nd_cap;
+        const int chunks = (nd + kDC - 1) / kDC;
+        const int per = (chunks + nsplit - 1) / nsplit;
+        float vq[4][32];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int k0 = 32 * b;
+            if (k0 < dim) load_span<VEC>(q + k0, min(32, ld - k0), vq[b]);
+        }
+        Top2 t;
+        t.s1 = t.s2 = kInf;
+        t.i1 = t.i2 = 0x7fffffff;
+        unsigned long long splits = en.splits;
+        while (splits != 0ull) {
+            const int sp = __ffsll((long long)splits) - 1;
+            splits &= splits - 1ull;
             const int lo = sp * per * kDC;
-            const int count = all ? min(nd, lo + per * kDC) - lo : n;
-            const int* __restrict__ list = cand_all + at * kCandCap;
-            for (int c = 0; c < count; c++) {
-                const int j = all ? lo + c : list[c];
+            const int hi = min(nd, lo + per * kDC);
+            for (int j = lo + tid; j < hi; j += 256) {
                 const float* r = D + (size_t)j * ld;
                 float acc = 0.0f;
 #pragma unroll
@@ -1444,12 +1534,26 @@ __global__ __launch_bounds__(128) void k_match_rank(PairTable tbl, int nq_cap, i
                 top2_insert(t, __builtin_fmaf(-2.0f, acc, qnv + dn[j]), j);
             }
         }
-        if (every_row || listed >= min(2, nd)) break;
-        every_row = true;
+        s_top[tid] = t;
+        __syncthreads();
+        for (int stride = 128; stride > 0; stride >>= 1) {
+            if (tid < stride) {
+                Top2 a = s_top[tid];
+                const Top2 o = s_top[tid + stride];
+                top2_insert(a, o.s1, o.i1);
+                top2_insert(a, o.s2, o.i2);
+                s_top[tid] = a;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const Top2 w = s_top[0];
+            const size_t o1 = (((size_t)en.pair * 2 + 1) * nq_cap + en.query) * 2;
+            part_s_all[o1] = w.s1; part_s_all[o1 + 1] = w.s2;
+            part_i_all[o1] = w.i1; part_i_all[o1 + 1] = w.i2;
+        }
+        __syncthreads();                    // s_top is reused by the next entry
     }
-    const size_t o = (size_t)blockIdx.y * part_stride + (size_t)i * 2;
-    part_s_all[o] = t.s1; part_s_all[o + 1] = t.s2;
-    part_i_all[o] = t.i1; part_i_all[o + 1] = t.i2;
 }
 
 // grid (ceil(nq_cap/128), npairs). A thread owns a query: it merges the splits'
@@ -1468,6 +1572,10 @@ __global__ __launch_bounds__(128) void k_match_finalize(PairTable tbl, int nq_ca
     const int* d_nd = pr.d_nd;
     int* __restrict__ idx2 = pr.d_idx2;
     float* __restrict__ dist2 = pr.d_dist2;
+    // nsplit < 0: -nsplit result slots per query that are all filled (the screened search: slot 0 from
+    // k_match_rank, slot 1 from k_match_overflow); otherwise one slot per database split
+    const bool all_slots = nsplit < 0;
+    if (all_slots) nsplit = -nsplit;
     part_s += (size_t)blockIdx.y * nsplit * nq_cap * 2;
     part_i += (size_t)blockIdx.y * nsplit * nq_cap * 2;
     const int nq = d_nq ? min(*d_nq, nq_cap) : nq_cap;
@@ -1480,7 +1588,7 @@ __global__ __launch_bounds__(128) void k_match_finalize(PairTable tbl, int nq_ca
     const int chunks = (nd + kDC - 1) / kDC;
     const int per = (chunks + nsplit - 1) / nsplit;
     for (int sp = 0; sp < nsplit; sp++) {
-        if (sp * per >= chunks) break;                  // this split had no database rows
+        if (!all_slots && sp * per >= chunks) break;    // this split had no database rows
         const size_t o = ((size_t)sp * nq_cap + i) * 2;
         const float2 ps = *reinterpret_cast<const float2*>(&part_s[o]);
         const int2 pi = *reinterpret_cast<const int2*>(&part_i[o]);
@@ -1594,7 +1702,8 @@ struct mif_matcher {
     int* d_idx = nullptr;
     float* d_dist = nullptr;
     float* d_score = nullptr;
-    unsigned int* work = nullptr;   // work-item counters: [0] exact search, [1], [2] screening passes
+    unsigned int* work = nullptr;   // counters: [0] exact search, [1], [2] screening passes, [3] queued queries
+    OverflowEntry* ovf = nullptr;   // [pairs][max_q] queries whose lists do not settle their answer
     // screening: largest database norm per pair; second smallest score / candidate count / candidates
     // per (pair, split, query), `screen_slots` of them
     unsigned int* dnmax = nullptr;  // [pairs]
@@ -1637,7 +1746,7 @@ void free_matcher(mif_matcher* m)
     (void)hipFree(m->d_q); (void)hipFree(m->d_db); (void)hipFree(m->d_idx); (void)hipFree(m->d_dist);
     (void)hipFree(m->d_score); (void)hipFree(m->work);
     (void)hipFree(m->dnmax); (void)hipFree(m->thr); (void)hipFree(m->cand_cnt); (void)hipFree(m->cand);
-    (void)hipFree(m->dbf);
+    (void)hipFree(m->dbf); (void)hipFree(m->ovf);
     for (int i = 0; i < kTableSlots; i++) {
         if (m->h_tbl[i]) (void)hipHostFree(m->h_tbl[i]);
         (void)hipFree(m->d_tbl[i]);
@@ -1762,6 +1871,14 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
                                    (double)nq * nd >= kTurnsMinScores;
                 const bool turns = m->dbf != nullptr && (turns_env ? atoi(turns_env) != 0 : large);
                 __bf16* dbf = m->dbf ? m->dbf + (size_t)base * m->rows_pad * (128 + 24) : nullptr;
+                // Pass 0 of the image-based kernel looks at every n-th chunk of a split only. The limit it
+                // leaves is looser, so a query's lists hold more rows (about 2 n more): n follows the
+                // number of lists a query's candidates spread over (measured: 16 splits take n = 4, 8 take
+                // 2, 4 take none; beyond 8 the lists overflow more often than the pass gets cheaper).
+                static const char* sample_env = getenv("MIF_MATCH_SAMPLE");                  // tuning override
+                const int per_split = ((nd + kDC - 1) / kDC + nsplit - 1) / nsplit;
+                const int sample = sample_env ? std::max(1, atoi(sample_env))
+                                              : (per_split >= 64 ? std::max(1, std::min(nsplit / 4, 8)) : 1);
 #define MIF_LAUNCH_SCREEN(KK, V, PASS)                                                                           \
     do {                                                                                                         \
         if (screen_v1)                                                                                           \
@@ -1776,7 +1893,7 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
             hipLaunchKernelGGL((k_match_screen4<KK, V, PASS>), dim3(m->blocks / 2), dim3(512), 0, st, tbl, np,  \
                                nq, nd, dim, ld, (const float*)qn, (const __bf16*)dbf, m->rows_pad,              \
                                (const unsigned int*)nmax, nsplit, thr, m->screen_slots, ccnt, cand,             \
-                               m->work + 1 + PASS);                                                              \
+                               m->work + 1 + PASS, sample);                                                      \
         }                                                                                                        \
         else if (wide)                                                                                           \
             hipLaunchKernelGGL((k_match_screen2<KK, V, PASS, 8>), dim3(m->blocks / 2), dim3(512), 0, st, tbl, np,  \
@@ -1802,14 +1919,19 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
                 }
 #undef MIF_LAUNCH_SCREEN
 #undef MIF_LAUNCH_LIMITS
-                if (vec)
-                    hipLaunchKernelGGL(k_match_rank<true>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim,
-                                       ld, (const float*)qn, (const float*)dn, nsplit, (const int*)ccnt, (const int*)cand, ps, pi,
-                                       nq * 2);
-                else
-                    hipLaunchKernelGGL(k_match_rank<false>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim,
-                                       ld, (const float*)qn, (const float*)dn, nsplit, (const int*)ccnt, (const int*)cand, ps, pi,
-                                       nq * 2);
+                // (work[3]: the number of queued queries; zeroed with the other counters above)
+#define MIF_LAUNCH_RANK(V)                                                                                       \
+    do {                                                                                                         \
+        hipLaunchKernelGGL(k_match_rank<V>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim, ld,  \
+                           (const float*)qn, (const float*)dn, nsplit, (const int*)ccnt, (const int*)cand, ps,  \
+                           pi, m->ovf + (size_t)base * m->max_q, m->work + 3);                                  \
+        hipLaunchKernelGGL(k_match_overflow<V>, dim3(2 * m->blocks), dim3(256), 0, st, tbl, nq, nd, dim, ld,     \
+                           (const float*)qn, (const float*)dn, nsplit,                                          \
+                           (const OverflowEntry*)(m->ovf + (size_t)base * m->max_q),                            \
+                           (const unsigned int*)(m->work + 3), ps, pi);                                         \
+    } while (0)
+                if (vec) MIF_LAUNCH_RANK(true); else MIF_LAUNCH_RANK(false);
+#undef MIF_LAUNCH_RANK
             } else {
 #define MIF_LAUNCH_PARTIAL(KS, V)                                                                              \
     hipLaunchKernelGGL((k_match_partial<KS, V>), dim3(m->blocks), dim3(256), 0, st, tbl, np, nq, nd, dim, ld,    \
@@ -1821,10 +1943,10 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
         }
         if (vec_db && vec_q)
             hipLaunchKernelGGL(k_match_finalize<true>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim,
-                               ld, screen ? 1 : nsplit, (const float*)ps, (const int*)pi);
+                               ld, screen ? -2 : nsplit, (const float*)ps, (const int*)pi);
         else
             hipLaunchKernelGGL(k_match_finalize<false>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim,
-                               ld, screen ? 1 : nsplit, (const float*)ps, (const int*)pi);
+                               ld, screen ? -2 : nsplit, (const float*)ps, (const int*)pi);
         if (filter_mode != 0)
             hipLaunchKernelGGL(k_match_filter, dim3(np), dim3(256), 0, st, tbl, nq, filter_mode);
     }
@@ -1991,6 +2113,7 @@ int mif_match_create_batched(int device, int max_query, int max_database, int ma
     if ((e = hipMalloc(&m->thr, 2 * m->screen_slots * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->cand_cnt, m->screen_slots * sizeof(int))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->cand, m->screen_slots * kCandCap * sizeof(int))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&m->ovf, P * max_query * sizeof(OverflowEntry))) != hipSuccess) return fail(e);
     // the bf16 image of the database rows for the screening passes of large searches (kTurnsMinScores);
     // a matcher too small for those has none, and without it (out of memory) the passes stage the fp32
     // rows themselves
