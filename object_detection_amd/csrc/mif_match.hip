@@ -745,7 +745,7 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
                                                        const unsigned int* __restrict__ dnmax_all, int nsplit,
                                                        float* __restrict__ t2_all, size_t s1_off,
                                                        int* __restrict__ cnt_all, int* __restrict__ cand_all,
-                                                       unsigned int* __restrict__ work_counter)
+                                                       unsigned int* __restrict__ work_counter, int sample)
 {
     constexpr int KP = K + 16;                 // contraction length with the norm's k-step
     constexpr int KS = KP / 16;                // matrix instructions per tile
@@ -887,6 +887,9 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
             *reinterpret_cast<bf16x8*>(&s_b[buf][tid * KPB + K + 8]) = zz;
         }
     };
+    // pass 0 may look at every `sample`-th chunk only (see k_match_screen4)
+    const int cs = PASS == 0 ? sample : 1;
+    const int c_last = c_lo + (c_hi - 1 - c_lo) / cs * cs;
     load_chunk(c_lo);
 
     // queries (B operands): lane holds q[qbase + 32 s + col][16 j + 8 half .. + 7] for every instruction j
@@ -968,7 +971,7 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
     auto chunk_step = [&](int c, int buf) {
         store_chunk(buf);
         __syncthreads();
-        load_chunk(min(c + 1, c_hi - 1));
+        load_chunk(min(c + cs, c_last));
         f32x16 acc00, acc01, acc10, acc11;      // [row tile][query set]
 #pragma unroll
         for (int r = 0; r < 16; r++) { acc00[r] = 0.0f; acc01[r] = 0.0f; acc10[r] = 0.0f; acc11[r] = 0.0f; }
@@ -998,9 +1001,9 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
         consider(acc10, c * kDC + 32, 0, full);
         consider(acc11, c * kDC + 32, 1, full);
     };
-    for (int c = c_lo; c < c_hi; c += 2) {
+    for (int c = c_lo; c < c_hi; c += 2 * cs) {
         chunk_step(c, 0);
-        if (c + 1 < c_hi) chunk_step(c + 1, 1);
+        if (c + cs < c_hi) chunk_step(c + cs, 1);
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; s2++) {
@@ -1871,14 +1874,17 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
                                    (double)nq * nd >= kTurnsMinScores;
                 const bool turns = m->dbf != nullptr && (turns_env ? atoi(turns_env) != 0 : large);
                 __bf16* dbf = m->dbf ? m->dbf + (size_t)base * m->rows_pad * (128 + 24) : nullptr;
-                // Pass 0 of the image-based kernel looks at every n-th chunk of a split only. The limit it
+                // Pass 0 of the second and third form looks at every n-th chunk of a split only. The limit it
                 // leaves is looser, so a query's lists hold more rows (about 2 n more): n follows the
                 // number of lists a query's candidates spread over (measured: 16 splits take n = 4, 8 take
                 // 2, 4 take none; beyond 8 the lists overflow more often than the pass gets cheaper).
                 static const char* sample_env = getenv("MIF_MATCH_SAMPLE");                  // tuning override
                 const int per_split = ((nd + kDC - 1) / kDC + nsplit - 1) / nsplit;
+                // Large searches only: with one list per query (frame batches) any sampling overflows lists
+                // (57.3 -> 57.7 ms per step at n = 2), and a few thousand queries do not repay the longer lists
+                // (2048 x 1 M rows: 2.5 -> 3.7 ms).
                 const int sample = sample_env ? std::max(1, atoi(sample_env))
-                                              : (per_split >= 64 ? std::max(1, std::min(nsplit / 4, 8)) : 1);
+                                              : (per_split >= 64 && large ? std::max(1, std::min(nsplit / 4, 8)) : 1);
 #define MIF_LAUNCH_SCREEN(KK, V, PASS)                                                                           \
     do {                                                                                                         \
         if (screen_v1)                                                                                           \
@@ -1898,11 +1904,13 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
         else if (wide)                                                                                           \
             hipLaunchKernelGGL((k_match_screen2<KK, V, PASS, 8>), dim3(m->blocks / 2), dim3(512), 0, st, tbl, np,  \
                                nq, nd, dim, ld, (const float*)qn, (const float*)dn, (const unsigned int*)nmax,   \
-                               nsplit, thr, m->screen_slots, ccnt, cand, m->work + 1 + PASS);                    \
+                               nsplit, thr, m->screen_slots, ccnt, cand, m->work + 1 + PASS,                    \
+                               sample);                                                                          \
         else                                                                                                     \
             hipLaunchKernelGGL((k_match_screen2<KK, V, PASS, 4>), dim3(m->blocks), dim3(256), 0, st, tbl, np,    \
                                nq, nd, dim, ld, (const float*)qn, (const float*)dn, (const unsigned int*)nmax,   \
-                               nsplit, thr, m->screen_slots, ccnt, cand, m->work + 1 + PASS);                    \
+                               nsplit, thr, m->screen_slots, ccnt, cand, m->work + 1 + PASS,                    \
+                               sample);                                                                          \
     } while (0)
 #define MIF_LAUNCH_LIMITS()                                                                                      \
     do {                                                                                                         \
