@@ -275,6 +275,11 @@ int mif_match_destroy(mif_matcher* m);
  * way; the switch exists to measure the two forms side by side. No counterpart in the reference. */
 int mif_match_set_screening(mif_matcher* m, int enable);
 
+/* How many times the screening of the matcher's last call contracted the queries with the whole
+ * database in bf16: 0 (searched in fp32 throughout), 2, or 1 + 1/n when the first pass looked at every
+ * n-th chunk of rows only (large searches). For throughput accounting; no counterpart in the reference. */
+int mif_match_last_screen_passes(mif_matcher* m, double* passes);
+
 /* Exact brute-force 2-nearest-neighbour search in L2; replaces the
  * cv::FlannBasedMatcher::match / knnMatch(k=2) calls of common/kpmatch.h:174-176
  * and 284-286. Row i of q / db starts at q + i*ld; only the first `dim` floats of
@@ -385,6 +390,8 @@ int mif_match_sharded_destroy(mif_match_sharded* h);
 int mif_match_sharded_ranks(const mif_match_sharded* h, int* nlocal, int* nranks, int* uses_rccl);
 /* mif_match_set_screening for every shard's matcher. */
 int mif_match_sharded_set_screening(mif_match_sharded* h, int enable);
+/* mif_match_last_screen_passes of the first local shard's matcher (all shards choose alike). */
+int mif_match_sharded_last_screen_passes(mif_match_sharded* h, double* passes);
 
 /* What one local rank brings to a search; all pointers are device addresses on that rank's GPU. */
 typedef struct mif_shard_io {

@@ -72,6 +72,7 @@ SYMBOLS = [
     ("mif_match_create_batched", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("mif_match_destroy", C.c_int, [_P]),
     ("mif_match_set_screening", C.c_int, [_P, C.c_int]),
+    ("mif_match_last_screen_passes", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("mif_match_top2_batch_device", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     ("mif_match_top2", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     ("mif_match_top2_scores", C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
@@ -82,6 +83,7 @@ SYMBOLS = [
     ("mif_match_sharded_destroy", C.c_int, [_P]),
     ("mif_match_sharded_ranks", C.c_int, [_P, _PI, _PI, _PI]),
     ("mif_match_sharded_set_screening", C.c_int, [_P, C.c_int]),
+    ("mif_match_sharded_last_screen_passes", C.c_int, [_P, C.POINTER(C.c_double)]),
     ("mif_match_sharded_search", C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int]),
     ("mif_match_sharded_sync", C.c_int, [_P]),
     ("mif_video_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),

@@ -1707,6 +1707,7 @@ struct mif_matcher {
     float* d_score = nullptr;
     unsigned int* work = nullptr;   // counters: [0] exact search, [1], [2] screening passes, [3] queued queries
     OverflowEntry* ovf = nullptr;   // [pairs][max_q] queries whose lists do not settle their answer
+    double last_passes = 0.0;       // contraction passes over the database the last call's screening made
     // screening: largest database norm per pair; second smallest score / candidate count / candidates
     // per (pair, split, query), `screen_slots` of them
     unsigned int* dnmax = nullptr;  // [pairs]
@@ -1847,6 +1848,7 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
             else
                 screen = false;
         }
+        m->last_passes = 0.0;
         if (nd > 0) {
             unsigned int* nmax = screen ? m->dnmax + base : nullptr;
             if (screen) MIF_HIP(hipMemsetAsync(nmax, 0, (size_t)np * sizeof(unsigned int), st));
@@ -1885,6 +1887,7 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
                 // (2048 x 1 M rows: 2.5 -> 3.7 ms).
                 const int sample = sample_env ? std::max(1, atoi(sample_env))
                                               : (per_split >= 64 && large ? std::max(1, std::min(nsplit / 4, 8)) : 1);
+                m->last_passes = 1.0 + 1.0 / (screen_v1 ? 1 : sample);
 #define MIF_LAUNCH_SCREEN(KK, V, PASS)                                                                           \
     do {                                                                                                         \
         if (screen_v1)                                                                                           \
@@ -2168,6 +2171,13 @@ int mif_match_set_screening(mif_matcher* m, int enable)
 {
     if (!m) { mif::set_error("mif_match_set_screening: NULL handle"); return MIF_ERR_INVALID_ARGUMENT; }
     m->screening = enable != 0;
+    return MIF_OK;
+}
+
+int mif_match_last_screen_passes(mif_matcher* m, double* passes)
+{
+    if (!m || !passes) { mif::set_error("mif_match_last_screen_passes: NULL argument"); return MIF_ERR_INVALID_ARGUMENT; }
+    *passes = m->last_passes;
     return MIF_OK;
 }
 

@@ -304,6 +304,15 @@ int mif_match_sharded_set_screening(mif_match_sharded* h, int enable)
     return MIF_OK;
 }
 
+int mif_match_sharded_last_screen_passes(mif_match_sharded* h, double* passes)
+{
+    if (!h || !passes || h->s.empty()) {
+        mif::set_error("mif_match_sharded_last_screen_passes: bad argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    return mif_match_last_screen_passes(h->s[0].matcher, passes);
+}
+
 int mif_match_sharded_search(mif_match_sharded* h, const mif_shard_io* io, int nq, int dim, int ld)
 {
     if (!h || !io) { mif::set_error("mif_match_sharded_search: NULL argument"); return MIF_ERR_INVALID_ARGUMENT; }

@@ -30,6 +30,12 @@ class Matcher:
         """False: plain fp32 search for every call (same results; for measurements)."""
         _lib.check(self._lib.mif_match_set_screening(self._h, 1 if enable else 0))
 
+    def last_screen_passes(self):
+        """bf16 contraction passes over the database made by the last call's screening (0, 2 or 1 + 1/n)."""
+        v = C.c_double()
+        _lib.check(self._lib.mif_match_last_screen_passes(self._h, C.byref(v)))
+        return v.value
+
     def top2(self, q, db, dim=None, return_scores=False):
         """q [nq, ld], db [nd, ld] float32 host arrays; only the first `dim` columns take part.
         Returns idx [nq, 2] int32 (-1 = missing) and dist [nq, 2] float32 (inf = missing); with
@@ -123,6 +129,12 @@ class ShardedMatcher:
 
     def set_screening(self, enable=True):
         _lib.check(self._lib.mif_match_sharded_set_screening(self._h, 1 if enable else 0))
+
+    def last_screen_passes(self):
+        """bf16 contraction passes over the database made by the last search's screening."""
+        v = C.c_double()
+        _lib.check(self._lib.mif_match_sharded_last_screen_passes(self._h, C.byref(v)))
+        return v.value
 
     def search_all(self, ios, nq, dim, ld):
         """ios: one dict per local rank with q, shard, rows, offset, idx2, dist2 and optionally stream."""
