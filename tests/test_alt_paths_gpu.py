@@ -56,12 +56,16 @@ def test_scale_space_levels_singly_or_in_pairs(tmp_path, mask):
 
 @pytest.mark.parametrize("env", [{"MIF_MATCH_SCREEN_V1": "1"}, {"MIF_MATCH_SCREEN_WIDE": "1"},
                                  {"MIF_MATCH_SCREEN_WIDE": "0"}, {"MIF_MATCH_SCREEN_TURNS": "1"},
-                                 {"MIF_MATCH_SCREEN_TURNS": "0"}])
+                                 {"MIF_MATCH_SCREEN_TURNS": "0"},
+                                 {"MIF_MATCH_SCREEN_TURNS": "1", "MIF_MATCH_SAMPLE": "3"},
+                                 {"MIF_MATCH_SCREEN_TURNS": "0", "MIF_MATCH_SAMPLE": "5"}])
 def test_screening_kernel_forms(tmp_path, env):
     """The screening passes exist in four forms (32 queries per wave with the norms added in the epilogue;
     64 queries per wave with the norms inside the contraction, in blocks of 4 or of 8 waves; the same
     contraction over a bf16 image of the database rows copied straight into LDS, which large searches use
-    by themselves and MIF_MATCH_SCREEN_TURNS=1 forces at any size): each must give the default's bits."""
+    by themselves and MIF_MATCH_SCREEN_TURNS=1 forces at any size): each must give the default's bits, also
+    when the first pass looks at every n-th chunk of rows only (MIF_MATCH_SAMPLE: what large searches do,
+    with a looser limit, longer candidate lists and queries handed to the overflow kernel)."""
     ref = _run(tmp_path, "default", {})
     alt = _run(tmp_path, "screen", env)
     for k in ("match_idx", "match_dist"):
