@@ -309,7 +309,8 @@ def test_screening_margin_against_adversarial_rounding():
 def test_million_row_database_through_64_screening_splits():
     """1024 queries against 1 048 576 rows (the row count of the 1 M x 1 M configuration): the database is
     cut into 64 splits of 16384 rows for the screening passes. Includes rows repeated 40 times inside one
-    split (that split's candidate list overflows and is ranked row by row; ties go to the lowest index),
+    split (that split's candidate list overflows and the query goes to the overflow kernel; ties go to the
+    lowest index),
     a pair of equal rows in different splits, and an exact copy as nearest row. Checked against the
     checker, and the plain fp32 search must return the same bits."""
     import torch
@@ -336,4 +337,6 @@ def test_million_row_database_through_64_screening_splits():
         torch.cuda.synchronize()
         assert np.array_equal(idx.cpu().numpy(), idx_o), screening
         assert np.array_equal(dist.cpu().numpy().view(np.uint32), dist_o.view(np.uint32)), screening
+        # two bf16 passes over the database (too few queries for a sampled first pass), or none
+        assert m.last_screen_passes() == (2.0 if screening else 0.0)
     assert (idx_o[:, 0] == perm).mean() > 0.98
