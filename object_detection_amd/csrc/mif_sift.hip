@@ -44,6 +44,10 @@ constexpr int kBlurTile = 64;      // output tile edge of the blur kernel
 // Small batches get more blocks per frame, so that the launch still fills the GPU.
 constexpr int kDescBlocks = 1024, kDescBlocksTotal = 65536;
 constexpr int kOriBlocks = 128, kOriBlocksTotal = 32768;
+#ifndef MIF_ORI_UNROLL
+#define MIF_ORI_UNROLL 2
+#endif
+constexpr int kOriUnroll = MIF_ORI_UNROLL;   // window pixels a lane of k_orientation handles per turn
 
 // Kernel constants as the reference's kernels see them: the host prints them
 // into -D options with 6 significant digits and OpenCL C parses them as double
@@ -1205,35 +1209,88 @@ __global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ k
             const int loops = wx * hy;
             const float2* img = grad + offset_py;
             // window pixel i = (i / wx + ymin, i % wx + xmin), i = lid, lid + 16, ...
-            // the window is clipped to [1, w-2] x [1, h-2], so every window pixel can be
-            // gathered; the next pixel's load is issued before the current one is processed
-            int yn = lid / wx + ymin;
-            int xn = lid % wx + xmin;
-            float2 gnext = (lid < loops) ? img[yn * w + xn] : make_float2(0.0f, 0.0f);
-            for (int i = lid; i < loops; i += kOriLanes) {
-                const int xx = xn, yy = yn;
-                const float2 g2 = gnext;
-                xn += kOriLanes;
-                while (xn > xmax) { xn -= wx; yn++; }
-                if (i + kOriLanes < loops) gnext = img[yn * w + xn];
-                if (xx > 0 && xx < w - 1 && yy > 0 && yy < h - 1) {
-                    const float ddx = (float)(xx - x), ddy = (float)(yy - y);
-                    const int sq_dist = (int)(ddx * ddx + ddy * ddy);
-                    if (sq_dist <= sq_thres) {
-                        const float grad = mif_fabsf(g2.x);
-                        const float theta = g2.y;
-                        // bin = round(36 (theta + pi) / (2 pi)) in double (sift.cpp:493), a monotone
-                        // step function of theta: a float estimate that is off by at most one,
-                        // corrected against the exact thresholds
-                        int bin = min(max((int)__builtin_fmaf(theta, 5.72957795130823f, 18.5f), 0), kOriBins);
-                        bin += (theta >= s_thr[bin + 1]) ? 1 : 0;
-                        bin -= (theta < s_thr[bin]) ? 1 : 0;
-                        bin = (bin < kOriBins) ? bin : 0;
-                        // sq_dist <= rad^2 with rad = round(4.5 sigma) and exp_factor = -0.5 / (1.5 sigma)^2:
-                        // the argument stays above -6
-                        hist[bin] += grad * mif_expf_bounded((float)sq_dist * exp_factor);
-                    }
+            // the window is clipped to [1, w-2] x [1, h-2], so every window pixel can be gathered.
+            // Several pixels per turn (i, i + 16, ...): a pixel costs the lane three LDS round trips in a row
+            // (two bin thresholds, then the histogram entry), and with 9.5 KB of histograms per wave only
+            // four waves share a SIMD, so those latencies are the kernel's time. Both thresholds of a
+            // pixel come with one read, the turn's reads go out together, and the gathers of the next
+            // turn's pixels are in flight meanwhile. A pixel outside the circle (or past the window's
+            // end) adds +0 to bin 0, which leaves every value a histogram can hold as it is.
+            auto step = [&](int& px, int& py) {
+                px += kOriLanes;
+                while (px > xmax) { px -= wx; py++; }
+            };
+            constexpr int U = kOriUnroll;            // window pixels per turn
+            int px[U], py[U];
+            float2 gn[U];
+            px[0] = lid % wx + xmin;
+            py[0] = lid / wx + ymin;
+#pragma unroll
+            for (int u = 1; u < U; u++) {
+                px[u] = px[u - 1];
+                py[u] = py[u - 1];
+                step(px[u], py[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                gn[u] = (lid + u * kOriLanes < loops) ? img[py[u] * w + px[u]] : make_float2(0.0f, 0.0f);
+            for (int i = lid; i < loops; i += U * kOriLanes) {
+                int xx[U], yy[U];
+                float2 gg[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) { xx[u] = px[u]; yy[u] = py[u]; gg[u] = gn[u]; }
+                px[0] = px[U - 1];
+                py[0] = py[U - 1];
+                step(px[0], py[0]);
+#pragma unroll
+                for (int u = 1; u < U; u++) {
+                    px[u] = px[u - 1];
+                    py[u] = py[u - 1];
+                    step(px[u], py[u]);
                 }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (i + (U + u) * kOriLanes < loops) gn[u] = img[py[u] * w + px[u]];
+                int bin[U], est[U];
+                float wgt[U], tlo[U], thi[U];
+                bool ok[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const float ddx = (float)(xx[u] - x), ddy = (float)(yy[u] - y);
+                    const int sq_dist = (int)(ddx * ddx + ddy * ddy);
+                    ok[u] = i + u * kOriLanes < loops && xx[u] > 0 && xx[u] < w - 1 && yy[u] > 0 && yy[u] < h - 1 &&
+                            sq_dist <= sq_thres;
+                    // bin = round(36 (theta + pi) / (2 pi)) in double (sift.cpp:493), a monotone step
+                    // function of theta: a float estimate that is off by at most one, corrected against
+                    // the exact thresholds of the estimate's bin
+                    est[u] = min(max((int)__builtin_fmaf(gg[u].y, 5.72957795130823f, 18.5f), 0), kOriBins);
+                    tlo[u] = s_thr[est[u]];
+                    thi[u] = s_thr[est[u] + 1];
+                    // sq_dist <= rad^2 with rad = round(4.5 sigma) and exp_factor = -0.5 / (1.5 sigma)^2: the
+                    // argument stays above -6 inside the circle (and above -12 in the window's corners)
+                    wgt[u] = mif_fabsf(gg[u].x) * mif_expf_bounded((float)sq_dist * exp_factor);
+                }
+                float hv[U], res[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const float theta = gg[u].y;
+                    int bn = est[u] + ((theta >= thi[u]) ? 1 : 0) - ((theta < tlo[u]) ? 1 : 0);
+                    bn = (bn < kOriBins) ? bn : 0;
+                    bin[u] = ok[u] ? bn : 0;
+                    wgt[u] = ok[u] ? wgt[u] : 0.0f;
+                    hv[u] = hist[bin[u]];
+                }
+                // the additions in window order: a pixel whose bin an earlier pixel of the turn has
+                // already met continues from that pixel's result
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    float from = hv[u];
+#pragma unroll
+                    for (int v = 0; v < u; v++) from = (bin[v] == bin[u]) ? res[v] : from;
+                    res[u] = from + wgt[u];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) hist[bin[u]] = res[u];
             }
         }
         __syncthreads();
