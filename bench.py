@@ -76,6 +76,7 @@ def parse_args(argv=None):
                     help="make the PCIe-inclusive schedule the timed region of the headline fields too (frames "
                          "start in pinned host memory, summaries end there); for profiling that schedule")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the value_host_to_host measurement")
+    ap.add_argument("--no-two-streams-leg", action="store_true", help="skip the value_two_streams measurement")
     ap.add_argument("--host-steps", type=int, default=5, help="timed steps of the host-to-host leg")
     ap.add_argument("--match-rows", type=int, default=1000000,
                     help="query rows = database rows of the matcher block (0 = skip it)")
@@ -241,6 +242,16 @@ class Pipeline:
         self._tables = {}
         self.step_no = 0
         self.pending = False
+
+    def enable_two_streams(self):
+        """From now on the two handles run on a stream each (both own the whole device) with a matcher
+        each, batch k's matcher waiting for batch k - 1's last frame: the kernels of two batches overlap."""
+        self.sync()
+        self.h[1].set_stream(None)
+        self.masked = [self.h[0].stream(), self.h[1].stream()]
+        self.m2 = [self.m, self.oda.Matcher(self.cap, self.cap, device=self.dev_index, max_pairs=self.B)]
+        self.split, self.serial = 256, True
+        self.mstream = self.torch.cuda.ExternalStream(self.masked[0], device=self.dev)
 
     def _pairs(self, k):
         """Pair table of batch k: queries in handle k % 2, database of frame 0 in snapshot (k - 1) % 3."""
@@ -693,6 +704,26 @@ def main():
             host_leg["verified"] = ok_h
             verified = bool(verified and ok_h)
 
+    # informational: the same resident-frames step with the two handles free-running on a stream each.
+    # Not `value`: the kernels of two batches then overlap in time, so no per-kernel duration (the roofline
+    # block, a rocprofv3 summary) says what a kernel achieves by itself any more.
+    two_streams = None
+    if not args.no_two_streams_leg and not args.host_frames and not args.no_match and not pipe.split \
+            and not args.serial and rank_devices.count(local_rank) == 1:
+        try:
+            pipe.enable_two_streams()
+            dt_two = timed_region(step_resident, 3, args.host_steps)
+            two_streams = {"value": args.batch * args.host_steps * world / dt_two, "unit": "frames/s",
+                           "steps": args.host_steps, "ms_per_step": dt_two / args.host_steps * 1e3,
+                           "window": "frames resident in HBM; two handles on a stream each, a matcher each, "
+                                     "batches side by side"}
+            if want is not None:
+                ok_t, _ = compare_frame1(pipe, want, match=True)
+                two_streams["verified"] = ok_t
+                verified = bool(verified and ok_t)
+        except RuntimeError as exc:                      # e.g. no memory for the second matcher
+            two_streams = {"skipped": repr(exc)}
+
     # yardstick measured on this GPU: a 1 GiB device-to-device copy (bytes read + bytes written)
     src_t = torch.empty(1 << 28, dtype=torch.float32, device=device)
     dst_t = torch.empty_like(src_t)
@@ -758,6 +789,7 @@ def main():
                                    "detector": float(stage[:, 2].sum()), "orient_desc": float(stage[:, 3].sum())},
             "matcher": None,
             "value_host_to_host": host_leg,
+            "value_two_streams": two_streams,
             "verified": verified,
             "verify_detail": verify_detail,
         }

@@ -193,6 +193,10 @@ def test_bench_line_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "frames/s" and c["sample"]
+    # the legs beside the headline (uploads from pinned memory; two free-running streams) ran and were checked
+    assert d["verified"] is True
+    for leg in ("value_host_to_host", "value_two_streams"):
+        assert d[leg]["value"] > 0 and d[leg]["verified"] is True, leg
 
 
 @pytest.mark.parametrize("geom", [(101, 67, 3, 3), (203, 131, 1, 2), (75, 49, 3, 4), (130, 51, 1, 3), (9, 40, 3, 2)])

@@ -15,7 +15,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 # the frame pipeline alone: no matcher block, no host-to-host leg, no CPU legs
-PIPE="--no-cpu-baseline --no-verify --no-host-leg --match-rows 0"
+PIPE="--no-cpu-baseline --no-verify --no-host-leg --no-two-streams-leg --match-rows 0"
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 
 if has bench; then
