@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity soak: the HIP SIFT path against the CPU checker (oracle/) on images of random sizes,
 channel counts and contents, single frames and small batches, with and without up_scale; every output must be
-bit-identical. Not part of the test suite (it runs for as long as --seconds says); a failure prints the case.
-usage: python tools/soak_sift.py --seconds 120 [--seed 1]"""
+bit-identical. Test infrastructure like the rest of this directory (it uses the checker), but not collected by
+pytest: it runs for as long as --seconds says; a failure prints the case.
+usage: python tests/soak_sift.py --seconds 120 [--seed 1]"""
 import argparse
 import os
 import sys
@@ -12,7 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import object_detection_amd as oda  # noqa: E402
 import oracle_lib as orc  # noqa: E402
 from synth import blob_image, dense_image  # noqa: E402
