@@ -114,7 +114,8 @@ int mif_stream_wait_stream(int device, void* waiter, void* signaller);
  * bit i = compute unit i in the driver's numbering, which deals consecutive bits to the device's XCDs in
  * turn: the low n bits are n / 8 compute units of every XCD). Two streams with disjoint masks run their
  * kernels side by side, each on its share of the device. No counterpart in the reference (its two devices
- * are a CPU and a GPU, clDriver.h:1311-1432). mif_stream_destroy waits for the stream's work first. */
+ * are a CPU and a GPU, clDriver.h:1311-1432). The mask must be one contiguous run of set bits (anything
+ * else is refused with MIF_ERR_INVALID_ARGUMENT). mif_stream_destroy waits for the stream's work first. */
 int mif_stream_create_masked(int device, const uint32_t* cu_mask, int words, void** stream);
 int mif_stream_destroy(int device, void* stream);
 

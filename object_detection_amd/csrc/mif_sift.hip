@@ -2339,6 +2339,19 @@ int mif_stream_create_masked(int device, const uint32_t* cu_mask, int words, voi
         mif::set_error("mif_stream_create_masked: bad argument");
         return MIF_ERR_INVALID_ARGUMENT;
     }
+    // one contiguous run of set bits only: a mask of every other bit made the runtime (ROCm 7.2) crash
+    // inside the stream creation
+    int first = -1, last = -1, set = 0;
+    for (int i = 0; i < 32 * words; i++)
+        if (cu_mask[i / 32] >> (i % 32) & 1u) {
+            if (first < 0) first = i;
+            last = i;
+            set++;
+        }
+    if (set == 0 || last - first + 1 != set) {
+        mif::set_error("mif_stream_create_masked: the mask must be one contiguous run of set bits");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
     mif::DeviceGuard guard(device);
     if (!guard.ok) { mif::set_error("mif_stream_create_masked: cannot select device %d", device); return MIF_ERR_HIP; }
     hipStream_t st = nullptr;

@@ -255,3 +255,5 @@ def test_extraction_on_a_stream_with_a_share_of_the_compute_units():
     finally:
         _lib.check(lib.mif_stream_destroy(0, st))
     assert lib.mif_stream_create_masked(0, None, 8, C.byref(st)) != 0
+    sparse = (C.c_uint32 * 8)(0x55555555, 0, 0, 0, 0, 0, 0, 0)
+    assert lib.mif_stream_create_masked(0, sparse, 8, C.byref(st)) != 0 and b"contiguous" in lib.mif_last_error()
