@@ -22,8 +22,17 @@ The one JSON line carries, beside the frames/s headline and its roofline block:
                       are sharded and the top-2 candidates gathered over RCCL by the library itself
   value_host_to_host  the same step with the frames starting in pinned host memory and the match
                       summaries ending there (PCIe included; never the headline value)
+  value_host_to_host_features
+                      the same, and every batch's keypoints, orientations and descriptors also land in pinned
+                      host memory (what SIFT::extract_features hands back, SIFT/sift.cpp:1889-1911), on a
+                      download stream beside the next batch's work
+  configs             the other configurations of BASELINE.json, each bounded to a few seconds and compared
+                      with the CPU checker: C1 SIFT box.pgm / scene.pgm (extract + match + homography, host
+                      to host, through the C++ demo), C2 the same pair through SURF plus a 1080p batch,
+                      C4 a batch of 4K single-channel frames; each with the CPU restatement timed beside it
   verified            frame 1 of the last timed batch compared with the CPU checker (oracle/): keypoint
                       counts per octave, good-match count and the matched indices; exit code 1 on mismatch
+  per_rank_ms_per_step  every rank's own time per step (the headline uses the slowest)
 """
 import argparse
 import ctypes
@@ -47,6 +56,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak
 # move (min_bytes_per_frame), so that it is a utilisation and stays below 1.
 ALG_UNFUSED_BYTES_PER_PX_OCTAVE = 104.0
 BLUR_TRAFFIC_FILE = os.path.join("profiles", "r02_blur_traffic.json")
+SURF_INTEGRAL_BYTES_PER_PX = 16.0   # row scan r4 + w4, column scan r4 + w4 (the reference moves 32 with its transposes)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+DEMO_DIR = os.path.join(ROOT, "object_detection_amd", "cpp", "build")
 
 
 def min_bytes_per_frame(px, channels):
@@ -77,7 +89,13 @@ def parse_args(argv=None):
                          "start in pinned host memory, summaries end there); for profiling that schedule")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the value_host_to_host measurement")
     ap.add_argument("--no-two-streams-leg", action="store_true", help="skip the value_two_streams measurement")
-    ap.add_argument("--host-steps", type=int, default=5, help="timed steps of the host-to-host leg")
+    ap.add_argument("--host-steps", type=int, default=5, help="timed steps of the host-to-host legs")
+    ap.add_argument("--no-feature-leg", action="store_true", help="skip the value_host_to_host_features measurement")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` block (SIFT / SURF box-scene pair, SURF 1080p batch, 4K batch)")
+    ap.add_argument("--config-batch", type=int, default=64, help="frames per step of the batched `configs` legs")
+    ap.add_argument("--config-steps", type=int, default=5, help="timed steps of the batched `configs` legs")
+    ap.add_argument("--pair-repeats", type=int, default=30, help="timed repeats of the box / scene legs")
     ap.add_argument("--match-rows", type=int, default=1000000,
                     help="query rows = database rows of the matcher block (0 = skip it)")
     ap.add_argument("--match-steps", type=int, default=2, help="timed passes per form of the matcher block")
@@ -130,19 +148,39 @@ def launch_ranks(args, argv):
     return rc
 
 
+def gather_per_rank(dist, value):
+    """[value of rank 0, value of rank 1, ...] on every rank (a list of one without a process group)."""
+    if dist is None:
+        return [value]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, value)
+    return out
+
+
 def run_launch_only(rank, world, local_rank):
-    """The process group without the GPU work: every rank reports its device index, rank 0 prints them."""
+    """The process group without the GPU work: every rank reports its device index and a time of its own,
+    rank 0 prints them in the fields the full run uses (config.rank_devices, per_rank_ms_per_step,
+    matcher.sharded), so that the launcher and the line's multi-rank fields can be checked on a machine
+    without GPUs."""
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group(backend="gloo")
-    devs = [local_rank]
+    group = dist if world > 1 else None
+    devs = gather_per_rank(group, local_rank)
+    t0 = time.perf_counter()
     if world > 1:
-        devs = [None] * world
-        dist.all_gather_object(devs, local_rank)
+        dist.barrier()
+    per_rank = gather_per_rank(group, (time.perf_counter() - t0) * 1e3)
     if rank == 0:
         print(json.dumps({"launch_only": True, "n_gpus": world,
+                          "frame_workers": frame_workers(512, world),
+                          "per_rank_ms_per_step": per_rank,
                           "config": {"world_size": dist.get_world_size() if world > 1 else 1,
-                                     "rank_devices": devs}}), flush=True)
+                                     "rank_devices": devs},
+                          # the full run fills this from the library's handle (mif_match_sharded_ranks)
+                          "matcher": {"sharded": {"nranks": len(per_rank), "nlocal": 1, "uses_rccl": None,
+                                                  "source": "launch-only: no GPU, no library handle"}}}),
+              flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -156,12 +194,18 @@ def _frame(job):
     return blob_image(width, height, seed=seed, channels=channels, shift=(2 * t, t), wrap=True)
 
 
-def make_frames(width, height, batch, rank, channels=3):
+def frame_workers(batch, world):
+    """Worker processes one rank renders its frames with: at most 8, and all ranks of a node together no
+    more than the machine has CPUs (every rank renders at the same time)."""
+    return max(1, min(8, batch, (os.cpu_count() or 1) // max(world, 1)))
+
+
+def make_frames(width, height, batch, rank, channels=3, world=1, seed=1234):
     """Frame t = the seeded blob field translated by (2t, t), wrapping around the frame so that the
     blob count (and with it the keypoint count, about 3000) is the same for every t. Rendered by a few worker processes
     (numpy only; called before anything touches the GPU)."""
-    jobs = [(width, height, 1234 + 100 * rank, t, channels) for t in range(batch)]
-    workers = min(8, batch)
+    jobs = [(width, height, seed + 100 * rank, t, channels) for t in range(batch)]
+    workers = frame_workers(batch, world)
     if workers > 1:
         import multiprocessing as mp
         # close + join, not the context manager: its exit terminates the workers with SIGTERM,
@@ -324,6 +368,81 @@ class Pipeline:
         self.mstream.synchronize()
 
 
+class FeatureDownload:
+    """What SIFT::extract_features hands back (SIFT/sift.cpp:1889-1911: keypoints, orientations and
+    descriptors in the caller's memory) for whole batches: after the feature phase of batch k the rows of all
+    its frames are packed back to back on the device (mif_sift_pack_results) and their offsets downloaded
+    on the compute stream (2 KB); once the host knows the row count it enqueues three copies of exactly
+    that many rows into pinned host memory on a download stream, which run beside the next batch's
+    kernels. Device staging and pinned buffers exist twice and alternate; the packing of batch k + 2
+    waits (on the device) for the download of batch k. The download stream never waits for an event, so
+    it cannot hold up a stream that shares its hardware queue."""
+
+    def __init__(self, pipe, torch, device, rows_per_frame):
+        B = pipe.B
+        self.pipe, self.torch, self.B = pipe, torch, B
+        R = self.max_rows = B * rows_per_frame
+
+        def dev(shape, dt=torch.float32):
+            return [torch.empty(shape, dtype=dt, device=device) for _ in range(2)]
+
+        def host(shape, dt=torch.float32):
+            return [torch.empty(shape, dtype=dt).pin_memory() for _ in range(2)]
+
+        self.d_kp, self.d_ori, self.d_des, self.d_off = dev((R, 4)), dev((R,)), dev((R, 128)), dev((B + 2,), torch.int32)
+        self.h_kp, self.h_ori, self.h_des, self.h_off = host((R, 4)), host((R,)), host((R, 128)), host((B + 2,), torch.int32)
+        self.dstream = torch.cuda.Stream(device=device)
+        self.ev_off = [torch.cuda.Event() for _ in range(2)]
+        self.ev_done = [None, None]
+        self.rows = [0, 0]
+        self.bytes = 0
+        self.pending = None                     # batch whose rows are packed but not yet on their way
+
+    def after_step(self):
+        """Call right after Pipeline.step(): packs the batch just enqueued and sends the previous one."""
+        k = self.pipe.step_no - 1
+        p = k % 2
+        cs = self.pipe.mstream                  # the compute stream
+        if self.ev_done[p] is not None:
+            cs.wait_event(self.ev_done[p])      # the staging arrays are free again
+        self.pipe.h[p].pack_results(self.B, self.d_kp[p].data_ptr(), self.d_ori[p].data_ptr(),
+                                    self.d_des[p].data_ptr(), self.d_off[p].data_ptr(), self.max_rows)
+        with self.torch.cuda.stream(cs):
+            self.h_off[p].copy_(self.d_off[p], non_blocking=True)
+        self.ev_off[p].record(cs)
+        self.fetch()
+        self.pending = k
+
+    def fetch(self):
+        if self.pending is None:
+            return
+        p, B = self.pending % 2, self.B
+        self.ev_off[p].synchronize()            # the batch's kernels have finished; the next one's are queued
+        n, held = int(self.h_off[p][B]), int(self.h_off[p][B + 1])
+        if held > n:
+            raise RuntimeError("a batch holds %d feature rows, the download buffers %d" % (held, self.max_rows))
+        with self.torch.cuda.stream(self.dstream):
+            self.h_kp[p][:n].copy_(self.d_kp[p][:n], non_blocking=True)
+            self.h_ori[p][:n].copy_(self.d_ori[p][:n], non_blocking=True)
+            self.h_des[p][:n].copy_(self.d_des[p][:n], non_blocking=True)
+        ev = self.torch.cuda.Event()
+        ev.record(self.dstream)
+        self.ev_done[p] = ev
+        self.rows[p] = n
+        self.bytes += n * (16 + 4 + 512) + (B + 2) * 4
+        self.pending = None
+
+    def finish(self):
+        self.fetch()
+        self.dstream.synchronize()
+
+    def frame(self, parity, f):
+        """(keypoints, orientations, descriptors) of frame f of the batch last downloaded with this parity."""
+        lo, hi = int(self.h_off[parity][f]), int(self.h_off[parity][f + 1])
+        return (self.h_kp[parity][lo:hi].numpy(), self.h_ori[parity][lo:hi].numpy(),
+                self.h_des[parity][lo:hi].numpy())
+
+
 # ------------------------------------------------------- checker-side pieces
 
 def good_rule(d0):
@@ -371,7 +490,7 @@ def checker_frame1(frames, match=True):
     rc = S.run(frames[1])
     counts = [S.count(o) for o in range(3)]
     des1 = S.all_features()[3]
-    out = {"status": rc, "counts": counts}
+    out = {"status": rc, "counts": counts, "features": S.all_features()}
     if match and len(des0) and len(des1):
         idx, dist = orc.match_top2(oda.pack_sift_rows(des1), oda.pack_sift_rows(des0))
         out["keep"] = good_rule(dist[:, 0])
@@ -449,8 +568,10 @@ def matcher_block(args, oda, torch, dev, local_rank, rank, world, dist, backend)
         def search():
             m.top2_batch_device(pair, n, rows, dim, dim, 0, stream=stream)
         how = "one GPU holds all rows"
+        sharded = None
     else:
         m = oda.ShardedMatcher.from_process_group(dist, local_rank, max_query=n, max_shard_rows=max(rows, 1))
+        sharded = m.ranks()                     # the library's own view: ranks in the communicator, RCCL or not
 
         def search():
             m.search(q.data_ptr(), n, db.data_ptr(), rows, lo, dim, dim, idx.data_ptr(), dst.data_ptr(),
@@ -487,6 +608,7 @@ def matcher_block(args, oda, torch, dev, local_rank, rank, world, dist, backend)
                     % (n, n, dim, how),
         "metric": "descriptor matches/sec", "unit": "matches/s", "n_gpus": world,
         "scaling": "strong" if world > 1 else None,
+        "sharded": sharded,
         "value": n / dt_scr, "ms_per_pass": dt_scr * 1e3,
         "value_exact_fp32": n / dt_exact, "ms_per_pass_exact_fp32": dt_exact * 1e3,
         "screened_equals_exact": same, "true_neighbour_recovered": hit,
@@ -549,6 +671,245 @@ def run_native(args, oda, torch, frames, local_rank, world, rank, dist):
                                      "good_matches_last_frame": res[-1].good_matches}}))
 
 
+# ------------------------------------------------- the other configurations
+
+def demo_pair_leg(kind, repeats):
+    """BASELINE.json configs[0] / configs[1]: box.pgm against scene.pgm through the C++ demo of the
+    reference's command line (`-m object scene`: extract both, match, good-match filter, homography),
+    run as a child process. `-r N` makes the demo repeat the sequence N times with its pipelines built and
+    report the mean host-to-host milliseconds of every step. Returns the parsed report (checked against
+    the CPU checker by check_pair_leg, after the GPU work)."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(DEMO_DIR, "demo_coopcl_sift" if kind == "sift" else "demo_coopcl_Surf")
+    if not os.path.exists(exe):
+        return {"error": "%s is missing: run `make -C object_detection_amd/cpp`" % exe}
+    box, scene = os.path.join(GOLDEN, "box.pgm"), os.path.join(GOLDEN, "scene.pgm")
+    with tempfile.TemporaryDirectory() as tmp:
+        rep = os.path.join(tmp, "report.json")
+        try:
+            out = subprocess.run([exe, "-m", box, scene, "-f", "1", "-o", rep, "-r", str(repeats)],
+                                 capture_output=True, text=True, timeout=180, cwd=tmp)
+        except subprocess.TimeoutExpired:
+            return {"error": "the demo did not finish within 180 s"}
+        if out.returncode != 0 or not os.path.exists(rep):
+            return {"error": "demo exit code %d: %s" % (out.returncode, (out.stderr or out.stdout)[-400:])}
+        with open(rep) as fh:
+            return json.load(fh)
+
+
+def check_pair_leg(kind, report, budget_s=4.0):
+    """The demo's report against the CPU checker run on the same two images, and the checker's own time for
+    the same steps (extraction of both images + matching; the homography is host code either way) as the
+    CPU restatement beside it."""
+    import oracle_lib as orc
+    import object_detection_amd as oda
+    if "error" in report:
+        return {"error": report["error"], "verified": False}
+    box, scene = orc.read_pnm(os.path.join(GOLDEN, "box.pgm")), orc.read_pnm(os.path.join(GOLDEN, "scene.pgm"))
+
+    def run_checker():
+        if kind == "sift":
+            feats = []
+            for img in (box, scene):
+                S = orc.SiftOracle(img.shape[1], img.shape[0])
+                S.run(img)
+                feats.append(S.all_features()[3])
+            idx, dist = orc.match_top2(oda.pack_sift_rows(feats[0]), oda.pack_sift_rows(feats[1]))
+            keep = good_rule(dist[:, 0])
+        else:
+            feats = []
+            for img in (box, scene):
+                S = orc.SurfOracle(img.shape[1], img.shape[0])
+                S.run(img)
+                feats.append(S.points()[:, 6:])
+            idx, dist = orc.match_top2(feats[0], feats[1])
+            keep = dist[:, 0] < np.float32(0.75) * dist[:, 1]
+        return feats, idx, keep
+
+    feats, idx, keep = run_checker()                          # warm (library load, first touch)
+    done, t0 = 0, time.perf_counter()
+    while done < 3 or (time.perf_counter() - t0 < budget_s and done < 200):
+        run_checker()
+        done += 1
+    cpu_ms = (time.perf_counter() - t0) / done * 1e3
+    tm = report.get("timing_ms", {})
+    want = np.stack([np.nonzero(keep)[0], idx[keep, 0]], 1).tolist()
+    got = [g[:2] for g in report["good_matches"]]
+    ok = got == want and tm.get("feats_object") == len(feats[0]) and tm.get("feats_scene") == len(feats[1])
+    ok = ok and bool(report["has_homography"]) and report["inliers"] >= 4
+    gpu_ms = tm.get("total")
+    return {
+        "workload": "%s box.pgm (324x223) vs scene.pgm (512x384): extract both, match, good-match filter, "
+                    "RANSAC homography; pixels in host memory -> results in host memory, through "
+                    "demo_coopcl_%s -m" % (kind.upper(), "sift" if kind == "sift" else "Surf"),
+        "ms_per_pair": gpu_ms, "ms_per_pair_min": tm.get("total_min"), "repeats": tm.get("repeats"),
+        "ms_steps": {k: tm.get(k) for k in ("extract_object", "extract_scene", "convert", "match", "homography")},
+        "keypoints": [tm.get("feats_object"), tm.get("feats_scene")],
+        "good_matches": len(got), "inliers": report["inliers"],
+        "scene_corners": report["scene_corners"],
+        "verified": bool(ok),
+        "cpu_baseline": {"value": cpu_ms, "unit": "ms per pair (extraction of both images + matching)",
+                         "cores": orc.lib().orc_get_threads(), "kind": "port",
+                         "sample": "%d repeats of the same pair through the OpenMP restatement (oracle/); the "
+                                   "homography (%.3f ms) is the same host code on both sides and is not "
+                                   "included" % (done, tm.get("homography") or 0.0)},
+        "gpu_over_cpu": (cpu_ms / (gpu_ms - (tm.get("homography") or 0.0))) if gpu_ms else None,
+    }
+
+
+def surf_batch_leg(args, oda, torch, device, local_rank, frames):
+    """BASELINE.json configs[1] at throughput: a batch of 1080p BGR frames resident in HBM through
+    mif_surf_enqueue_batch; frames/s, the integral image's achieved bandwidth against 16 B/px, frame 1
+    compared with the CPU checker, and the checker's own rate beside it."""
+    import oracle_lib as orc
+    B, w, h = args.config_batch, 1920, 1080
+    # `frames`: two rendered 1080p BGR frames, repeated to fill the batch
+    px = torch.from_numpy(frames).to(device).repeat((B + 1) // 2, 1, 1, 1)[:B].contiguous()
+    ex = oda.SurfExtractor(w, h, 3, device=local_rank, batch=B)
+    for _ in range(2):
+        ex.enqueue_batch(px.data_ptr(), B)
+    ex.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.config_steps):
+        ex.enqueue_batch(px.data_ptr(), B)
+    ex.sync()
+    dt = (time.perf_counter() - t0) / args.config_steps
+    ex.set_timing(True)
+    stage = np.zeros(len(ex.STAGES))
+    for _ in range(args.config_steps):
+        ex.enqueue_batch(px.data_ptr(), B)
+        stage += ex.stage_times()
+    stage /= args.config_steps
+    ex.set_timing(False)
+    pts, raw = ex.copy_points(1)
+    S = orc.SurfOracle(w, h)
+    t0 = time.perf_counter()
+    n = S.run(frames[1])
+    cpu_s = time.perf_counter() - t0
+    P = S.points()
+    ok = len(pts) == n and raw == S.raw_count()
+    ok = ok and np.array_equal(ex.integral(1).view(np.uint32), S.integral().view(np.uint32))
+    if ok and n:
+        ok = bool(np.array_equal(pts["descriptor"].view(np.uint32), P[:, 6:].view(np.uint32)) and
+                  np.array_equal(pts["orientation"].view(np.uint32), P[:, 3].view(np.uint32)) and
+                  np.array_equal(pts["x"].view(np.uint32), P[:, 0].view(np.uint32)))
+    done, t0 = 1, time.perf_counter()
+    while time.perf_counter() - t0 < 3.0 and done < 40:
+        S.run(frames[done % 2])
+        done += 1
+    cpu_fps = (done - 1) / (time.perf_counter() - t0) if done > 1 else 1.0 / cpu_s
+    integ = SURF_INTEGRAL_BYTES_PER_PX * w * h * B / (stage[0] * 1e-3) / 1e9
+    return {
+        "workload": "SURF extraction of %d synthetic 1920x1080 BGR frames per step, resident in HBM "
+                    "(mif_surf_enqueue_batch)" % B,
+        "value": B / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "steps": args.config_steps,
+        "points_frame1": int(n),
+        "stage_ms_per_batch": {k: float(v) for k, v in zip(ex.STAGES, stage)},
+        "roofline": {"bound": "hbm", "kernel": "integral image (row scan + column scan)", "achieved": integ,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": integ / HBM_PEAK_GBS,
+                     "alg_bytes_per_px": SURF_INTEGRAL_BYTES_PER_PX, "traffic": None},
+        "verified": bool(ok),
+        "cpu_baseline": {"value": cpu_fps, "unit": "frames/s", "cores": orc.lib().orc_get_threads(), "kind": "port",
+                         "sample": "%d frames 1920x1080 BGR through the OpenMP restatement of the SURF pipeline "
+                                   "(oracle/)" % max(done - 1, 1)},
+    }
+
+
+def sift_4k_leg(args, oda, torch, device, local_rank, frames_16):
+    """BASELINE.json configs[3] on one GPU: a batch of 4K single-channel frames resident in HBM, SIFT
+    extraction only; frames/s, the scale-space launches against the HBM peak, frame 1 compared with the
+    CPU checker and the checker's own rate beside it."""
+    import oracle_lib as orc
+    B, w, h = args.config_batch, 3840, 2160
+    reps = (B + len(frames_16) - 1) // len(frames_16)
+    px = torch.from_numpy(frames_16).to(device).repeat(reps, 1, 1)[:B].contiguous()
+    ex = oda.SiftExtractor(w, h, 1, device=local_rank, batch=B)
+    for _ in range(2):
+        ex.enqueue(px.data_ptr(), B)
+    ex.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.config_steps):
+        ex.enqueue(px.data_ptr(), B)
+    ex.sync()
+    dt = (time.perf_counter() - t0) / args.config_steps
+    ex.set_timing(True)
+    ex.enqueue(px.data_ptr(), B)
+    stage = ex.stage_times()
+    ex.set_timing(False)
+    opx = [h_ * w_ for (w_, h_, _) in (ex.octave_info(o) for o in range(3))]
+    blur_ms = float(stage[:, 1].sum())
+    achieved = min_bytes_per_frame(opx, 1) * B / (blur_ms * 1e-3) / 1e9
+    rc, feat = ex.copy_results(1)
+    S = orc.SiftOracle(w, h, 1)
+    t0 = time.perf_counter()
+    rc_o = S.run(frames_16[1 % len(frames_16)])
+    cpu_s = time.perf_counter() - t0
+    kp, octs, ori, des = S.all_features()
+    ok = rc == rc_o and feat.counts == [S.count(o) for o in range(3)]
+    ok = ok and np.array_equal(feat.keypoints.view(np.uint32), kp.view(np.uint32))
+    ok = ok and np.array_equal(feat.orientations.view(np.uint32), ori.view(np.uint32))
+    ok = ok and np.array_equal(feat.descriptors.view(np.uint32), des.view(np.uint32))
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 3.0 and done < 40:
+        S.run(frames_16[done % len(frames_16)])
+        done += 1
+    cpu_fps = done / (time.perf_counter() - t0) if done else 1.0 / cpu_s
+    return {
+        "workload": "SIFT extraction (keypoints, orientations, descriptors) of %d synthetic 3840x2160 "
+                    "single-channel frames per step, resident in HBM (%d distinct frames, seed 4321, repeated "
+                    "to fill the batch)" % (B, len(frames_16)),
+        "value": B / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "steps": args.config_steps,
+        "keypoints_frame1": feat.counts,
+        "stage_ms_per_batch": {"scale_space": blur_ms, "detector": float(stage[:, 2].sum()),
+                               "orient_desc": float(stage[:, 3].sum())},
+        "roofline": {"bound": "hbm", "kernel": "k_blur_level / k_blur_pair", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "alg_bytes_per_frame": min_bytes_per_frame(opx, 1), "traffic": None},
+        "verified": bool(ok),
+        "cpu_baseline": {"value": cpu_fps, "unit": "frames/s", "cores": orc.lib().orc_get_threads(), "kind": "port",
+                         "sample": "%d frames 3840x2160 gray, extraction only, OpenMP restatement (oracle/)"
+                                   % max(done, 1)},
+    }
+
+
+# ---------------------------------------------------- guarded matcher block
+
+def guarded_matcher_block(run_block, rank, world, timeout_s, out, emit=print, leave=os._exit):
+    """Runs the matcher block of a multi-rank run under a watchdog. Returns (block, ok, failed).
+
+    The block contains the library's RCCL collective: a rank that fails before it leaves the others
+    waiting. So a failure on any rank must end the whole job with a non-zero exit code, rank 0 included:
+      * the watchdog (world > 1) fires after `timeout_s`: rank 0 prints the line as it stands with an
+        `error` field, then every rank leaves with code 4 through `leave` (no barrier, no clean-up: the
+        other ranks may be stuck inside the collective);
+      * the block raises: ok = False and failed = True; the caller prints the line, skips the final barrier
+        and exits non-zero, which makes the launcher stop the other ranks."""
+    import threading
+
+    def give_up():
+        if rank == 0 and out is not None:
+            out["matcher"] = {"error": "the sharded search did not finish within %d s" % timeout_s}
+            emit(json.dumps(out), flush=True)
+        leave(4)
+
+    dog = threading.Timer(timeout_s, give_up) if world > 1 else None
+    if dog is not None:
+        dog.daemon = True
+        dog.start()
+    try:
+        blk, ok = run_block()
+        failed = False
+    except Exception as exc:
+        if world == 1:
+            raise
+        blk, ok, failed = {"error": repr(exc)}, False, True
+    finally:
+        if dog is not None:
+            dog.cancel()
+    return blk, ok, failed
+
+
 # ---------------------------------------------------------------------- main
 
 def main():
@@ -561,7 +922,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.launch_only:
         return run_launch_only(rank, world, local_rank)
-    frames_np = make_frames(args.width, args.height, args.batch, rank, args.channels)      # before the GPU is initialised
+    # everything that forks or starts a child does so before the GPU is initialised
+    pair_legs = None
+    if rank == 0 and not args.no_configs:
+        pair_legs = {"C1_sift_box_scene": demo_pair_leg("sift", args.pair_repeats),
+                     "C2_surf_box_scene": demo_pair_leg("surf", args.pair_repeats)}
+    frames_np = make_frames(args.width, args.height, args.batch, rank, args.channels, world)
+    frames_4k, frames_surf = None, None
+    if rank == 0 and not args.no_configs:
+        frames_surf = frames_np[:2] if frames_np.shape[1:] == (1080, 1920, 3) and len(frames_np) >= 2 else \
+            np.stack([_frame((1920, 1080, 1234, t, 3)) for t in range(2)])
+        # 16 distinct 4K frames (seed 4321 + frame), repeated to fill the batch: rendering 64 would take longer
+        # than measuring them, and frames of an extraction-only batch are independent
+        frames_4k = make_frames(3840, 2160, min(16, args.config_batch), 0, 1, world, seed=4321)
     import torch
     import object_detection_amd as oda
     if not torch.cuda.is_available():
@@ -634,10 +1007,16 @@ def main():
             with torch.cuda.stream(pipe.mstream):
                 hs["host_summ"][(k - 1) % 2].copy_(pipe.summ[(k - 1) % 2], non_blocking=True)
 
-    def timed_region(step, warmup, steps):
-        """Barrier + synchronize on both sides of exactly `steps` steps; max over the ranks."""
+    own_seconds = {}
+
+    def timed_region(step, warmup, steps, finish=None, name=None):
+        """Barrier + synchronize on both sides of exactly `steps` steps; max over the ranks. `finish` runs
+        inside the timed region after the last step (work a leg still owes for its last batch). The rank's
+        own time up to its synchronize, before the closing barrier, is kept under `name`."""
         for _ in range(warmup):
             step()
+        if finish is not None:
+            finish()
         pipe.sync()
         torch.cuda.synchronize()
         barrier()
@@ -645,8 +1024,12 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        if finish is not None:
+            finish()
         pipe.sync()
         torch.cuda.synchronize()
+        if name:
+            own_seconds[name] = time.perf_counter() - t0
         barrier()
         return max_over_ranks(time.perf_counter() - t0)
 
@@ -656,7 +1039,8 @@ def main():
     pipe.sync()
     for h in pipe.h:
         h.set_timing(True)
-    dt_max = timed_region(step, 0, args.steps)
+    dt_max = timed_region(step, 0, args.steps, name="headline")
+    per_rank_ms = gather_per_rank(dist, own_seconds["headline"] / args.steps * 1e3)
 
     # stage times of the last two batches of the timed region (one per handle), measured with HIP events on
     # the handles' own streams; blur_level is the dominant bandwidth kernel (6 launches per octave)
@@ -703,6 +1087,40 @@ def main():
             ok_h, _ = compare_frame1(pipe, want, match=True)
             host_leg["verified"] = ok_h
             verified = bool(verified and ok_h)
+
+    # the same, and every batch's features (keypoints, orientations, descriptors) go back to pinned host
+    # memory as well: the window of the reference's call, pixels in host memory -> features in host memory
+    feature_leg = None
+    if host_leg is not None and not args.no_feature_leg and not pipe.split and not pipe.serial:
+        fd = FeatureDownload(pipe, torch, device, max(pipe.cap // 4, 1))
+
+        def step_host_features():
+            step_host()
+            fd.after_step()
+
+        fd.bytes = 0
+        dt_feat = timed_region(step_host_features, 2, args.host_steps, finish=fd.finish)
+        # bytes of the timed steps only: the warm-up's are counted up to its finish()
+        feat_bytes = fd.bytes * args.host_steps / (args.host_steps + 2)
+        feature_leg = {"value": args.batch * args.host_steps * world / dt_feat, "unit": "frames/s",
+                       "steps": args.host_steps, "ms_per_step": dt_feat / args.host_steps * 1e3,
+                       "upload_GBps_per_gpu": args.batch * frames_np[0].nbytes * args.host_steps / dt_feat / 1e9,
+                       "download_GBps_per_gpu": feat_bytes / dt_feat / 1e9,
+                       "feature_rows_per_batch": fd.rows[pipe.last()],
+                       "download_MB_per_frame": fd.rows[pipe.last()] * 532 / args.batch / 1e6,
+                       "window": "pinned host frames -> upload -> extract + match -> keypoints, orientations, "
+                                 "descriptors (packed per batch, mif_sift_pack_results) and match summaries in "
+                                 "pinned host memory"}
+        if want is not None:
+            ok_f, _ = compare_frame1(pipe, want, match=True)
+            kp_h, ori_h, des_h = fd.frame(pipe.last(), 1)
+            kp_w, _, ori_w, des_w = want["features"]
+            ok_f = bool(ok_f and np.array_equal(kp_h.view(np.uint32), kp_w.view(np.uint32)) and
+                        np.array_equal(ori_h.view(np.uint32), ori_w.view(np.uint32)) and
+                        np.array_equal(des_h.view(np.uint32), des_w.view(np.uint32)))
+            feature_leg["verified"] = ok_f
+            verified = bool(verified and ok_f)
+        del fd
 
     # informational: the same resident-frames step with the two handles free-running on a stream each.
     # Not `value`: the kernels of two batches then overlap in time, so no per-kernel duration (the roofline
@@ -789,6 +1207,8 @@ def main():
                                    "detector": float(stage[:, 2].sum()), "orient_desc": float(stage[:, 3].sum())},
             "matcher": None,
             "value_host_to_host": host_leg,
+            "value_host_to_host_features": feature_leg,
+            "per_rank_ms_per_step": per_rank_ms,
             "value_two_streams": two_streams,
             "verified": verified,
             "verify_detail": verify_detail,
@@ -796,51 +1216,54 @@ def main():
     else:
         out = None
 
-    # The other half of the metric: descriptor matches/s of the big search (the frame pipeline's memory is
-    # released first). With several ranks the block contains the library's own RCCL collective; should that
-    # ever stall, a watchdog on every rank ends the run with the line as it stands rather than hanging it.
-    match_ok = True
+    # The frame pipeline's memory is released before the other blocks. The pinned buffers go first: torch's
+    # host allocator records an event on every stream that used them when they are freed, and the handles'
+    # stream is gone once the pipeline is.
+    pipe.sync()
+    host_state.clear()
+    del pipe, frames, step, timed
+    torch.cuda.empty_cache()
+
+    # The other half of the metric: descriptor matches/s of the big search. With several ranks the block
+    # contains the library's own RCCL collective; a stall or a failure there ends the whole job with a
+    # non-zero exit code on every rank (guarded_matcher_block), after rank 0 has printed the line.
+    match_ok, match_failed = True, False
     if args.match_rows > 0 and not args.no_match:
-        pipe.sync()
-        # the pinned buffers go first: torch's host allocator records an event on every stream that used
-        # them when they are freed, and the handles' stream is gone once the pipeline is
-        host_state.clear()
-        del pipe, frames, step, timed
-        torch.cuda.empty_cache()
         if world > 1 and backend != "nccl":
             blk = {"skipped": "rehearsal with ranks sharing a GPU: RCCL needs one GPU per rank"}
         else:
-            import threading
-
-            def give_up():
-                if rank == 0:
-                    out["matcher"] = {"error": "the sharded search did not finish within %d s" % args.match_timeout}
-                    print(json.dumps(out), flush=True)
-                os._exit(0 if rank == 0 else 3)
-
-            dog = threading.Timer(args.match_timeout, give_up) if world > 1 else None
-            if dog is not None:
-                dog.daemon = True
-                dog.start()
-            try:
-                blk, match_ok = matcher_block(args, oda, torch, device, local_rank, rank, world, dist, backend)
-            except Exception as exc:                      # reported in the line; the headline stands
-                if world == 1:
-                    raise
-                blk, match_ok = {"error": repr(exc)}, True
-            if dog is not None:
-                dog.cancel()
+            blk, match_ok, match_failed = guarded_matcher_block(
+                lambda: matcher_block(args, oda, torch, device, local_rank, rank, world, dist, backend),
+                rank, world, args.match_timeout, out)
         if rank == 0:
             out["matcher"] = blk
+
+    # The other configurations of BASELINE.json (one GPU; the pair legs ran as child processes above)
+    configs_ok = True
+    if rank == 0 and world == 1 and not args.no_configs:
+        cfg = {"C1_sift_box_scene": check_pair_leg("sift", pair_legs["C1_sift_box_scene"]),
+               "C2_surf_box_scene": check_pair_leg("surf", pair_legs["C2_surf_box_scene"]),
+               "C2_surf_1080p_batch": surf_batch_leg(args, oda, torch, device, local_rank, frames_surf),
+               "C3_sift_1080p_sequence": "the headline fields of this line (value, roofline, cpu_baseline, verified)",
+               "C4_sift_4k_batch": sift_4k_leg(args, oda, torch, device, local_rank, frames_4k),
+               "C5_match_1Mx1M": "the `matcher` block of this line"}
+        configs_ok = all(v.get("verified", False) for v in cfg.values() if isinstance(v, dict))
+        out["configs"] = cfg
 
     rc = 0
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_seconds, match=not args.no_match)
         print(json.dumps(out), flush=True)
-        if verified is False or not match_ok:
-            print("bench.py: results differ from the CPU checker or between the two matcher forms", file=sys.stderr)
+        if verified is False or not match_ok or not configs_ok:
+            print("bench.py: results differ from the CPU checker or between the two matcher forms, or the "
+                  "matcher block failed", file=sys.stderr)
             rc = 1
+    if match_failed:
+        # this rank's part of the sharded search failed: the other ranks may be inside the collective, so
+        # no barrier; the non-zero exit makes the launcher stop them
+        sys.stdout.flush()
+        os._exit(5)
     barrier()
     if dist is not None:
         dist.destroy_process_group()

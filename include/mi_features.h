@@ -105,6 +105,19 @@ int mif_sift_enqueue_features(mif_sift* s, int want_descriptors);
  * video caller matches the next batch's first frame against (SIFT/main.cpp:103-153 keeps the
  * previous frame's features on the host). */
 int mif_sift_snapshot_frame(mif_sift* s, int frame, float* d_descriptors, int32_t* d_count);
+/* The readback of SIFT/sift.cpp:1889-1911 (features(), orientations() and descriptors() appended octave
+ * by octave to the caller's vectors) for a whole batch: packs the rows of the first nframes frames of the
+ * last enqueued batch back to back -- frame after frame, every frame octave-major as mif_sift_extract
+ * returns it -- into caller-owned device arrays, in stream order on the handle's stream, so that a
+ * batch's results leave the GPU with one copy per array instead of one per frame.
+ *   d_keypoints     max_rows x 4 floats, 16-byte aligned
+ *   d_orientations  max_rows floats, or NULL together with d_descriptors (detector only)
+ *   d_descriptors   max_rows x 128 floats, 16-byte aligned
+ *   d_offsets       int32[nframes + 2]: [f] = first packed row of frame f, [nframes] = rows packed,
+ *                   [nframes + 1] = rows the frames hold (larger than [nframes] when max_rows cut the
+ *                   batch short: the surplus rows are dropped from the end) */
+int mif_sift_pack_results(mif_sift* s, int nframes, float* d_keypoints, float* d_orientations, float* d_descriptors,
+                          int32_t* d_offsets, int max_rows);
 /* Orders two streams of the caller's: everything enqueued on `waiter` after this call runs after
  * everything enqueued on `signaller` before it. No counterpart in the reference, whose driver
  * chains tasks with add_dependence (clDriver.h); streams are HIP stream handles (mif_sift_stream). */
@@ -114,8 +127,10 @@ int mif_stream_wait_stream(int device, void* waiter, void* signaller);
  * bit i = compute unit i in the driver's numbering, which deals consecutive bits to the device's XCDs in
  * turn: the low n bits are n / 8 compute units of every XCD). Two streams with disjoint masks run their
  * kernels side by side, each on its share of the device. No counterpart in the reference (its two devices
- * are a CPU and a GPU, clDriver.h:1311-1432). The mask must be one contiguous run of set bits (anything
- * else is refused with MIF_ERR_INVALID_ARGUMENT). mif_stream_destroy waits for the stream's work first. */
+ * are a CPU and a GPU, clDriver.h:1311-1432). The mask must be one contiguous run of at least 8 set
+ * bits (so that every XCD keeps a compute unit) below the device's compute-unit count; anything else is
+ * refused with MIF_ERR_INVALID_ARGUMENT before the runtime is called (a mask of every other bit crashed
+ * ROCm 7.2 inside hipExtStreamCreateWithCUMask). mif_stream_destroy waits for the stream's work first. */
 int mif_stream_create_masked(int device, const uint32_t* cu_mask, int words, void** stream);
 int mif_stream_destroy(int device, void* stream);
 
@@ -139,7 +154,9 @@ void* mif_sift_stream(mif_sift* s);
  * whose work is ordered one after the other anyway -- the two handles a video pipeline alternates
  * between -- can share one stream: a process has few hardware queues (4 by default) for all its
  * streams, and streams that share a queue wait behind each other's kernels, e.g. an upload behind a
- * matcher. Waits for what the handle has enqueued so far. No counterpart in the reference. */
+ * matcher. Waits for what the handle has enqueued so far. The stream stays the caller's: it must
+ * outlive the handle, or be detached with mif_sift_set_stream(s, NULL) before it is destroyed (every
+ * later call on the handle enqueues on it or waits for it). No counterpart in the reference. */
 int mif_sift_set_stream(mif_sift* s, void* stream);
 /* Makes everything enqueued on `waiter` (a hipStream_t) from now on wait until the pixels of the batch
  * last enqueued on s have been read (they are read while the first octave's scale space is built; the
@@ -255,6 +272,16 @@ void* mif_surf_stream(mif_surf* s);
 int mif_surf_device_results(mif_surf* s, void** d_pos, void** d_scale, void** d_laplacian, void** d_orientation,
                             void** d_descriptors, void** d_counts);
 
+/* Per-stage GPU timing, the counterpart of ccl_surf::write_task_times_to_file (ccl_surf.h:32,
+ * ccl_surf.cpp:859-878: one record per task). While enabled, every enqueue records hipEvents on the
+ * handle's stream at the stage boundaries; mif_surf_stage_times waits for the stream and returns the last
+ * batch's milliseconds per stage: 0 integral image (scan, transpose, scan, transpose in the reference),
+ * 1 the eight hessian_det layers, 2 non_max_supression and the point list, 3 getOrientationStep1/2,
+ * 4 createDescriptors + normalizeDescriptors and the packing of the Ipoint records. */
+#define MIF_SURF_STAGES 5
+int mif_surf_set_timing(mif_surf* s, int enable);
+int mif_surf_stage_times(mif_surf* s, float ms[MIF_SURF_STAGES]);
+
 /* Probes for tests: the integral image (width*height floats) and one response
  * layer (responses / laplacians, either may be NULL) of the last frame. */
 int mif_surf_copy_integral(mif_surf* s, float* out);
@@ -304,15 +331,17 @@ int mif_match_top2_device(mif_matcher* m, const float* d_q, int nq, const int32_
                           int nd, const int32_t* d_nd, int dim, int ld, int32_t* d_idx2, float* d_dist2,
                           void* stream);
 
-/* The same search as mif_match_top2_device for callers that cannot allocate: code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc. No counterpart in the reference.
+/* The same search as mif_match_top2_device for callers that cannot allocate: tight serving loops,
+ * harnesses that forbid hipMalloc, code that is about to be captured into a HIP graph (capture itself
+ * has not been tested; make one call outside the capture first, which looks up what the later calls
+ * reuse). No counterpart in the reference.
  * There is no handle: the workspace (pair table, work counters, row norms, per-split partial winners)
  * is one fixed array of 4.3 MB in device memory that every GPU the library runs on holds until the
  * process ends, so a call is limited to MIF_NOALLOC_MAX_QUERY query rows and
  * MIF_NOALLOC_MAX_DATABASE database rows (MIF_ERR_CAPACITY beyond; use a mif_matcher then). The call
  * enqueues kernels and one memset on `stream` (a hipStream_t of `device`, NULL = default) and calls no
  * hipMalloc / hipFree or allocating library routine; the first call on a device looks the array's
- * address up. Always the plain fp32 search; results are the bits mif_match_top2_device returns.
+ * address and the device's compute-unit count up, later calls query nothing. Always the plain fp32 search; results are the bits mif_match_top2_device returns.
  * All calls on one GPU share the array: calls that may overlap on one GPU (different streams, different
  * threads) race and must be serialised by the caller. */
 #define MIF_NOALLOC_MAX_QUERY 4096
@@ -402,9 +431,10 @@ typedef struct mif_shard_io {
     int32_t global_offset; /* index of the shard's first row in the whole database */
     int32_t* d_idx2;       /* [nq][2] out: GLOBAL row indices of the two nearest rows, -1 when missing */
     float* d_dist2;        /* [nq][2] out: their Euclidean distances, +inf when missing */
-    void* stream;          /* hipStream_t to enqueue on; NULL = a stream the handle owns for this rank
-                            * (mif_match_sharded_sync waits for those). Keep one stream per rank from call
-                            * to call: the handle's buffers are reused in stream order. */
+    void* stream;          /* hipStream_t to enqueue on; NULL = a stream the handle owns for this rank.
+                            * Keep one stream per rank from call to call: the handle's buffers are reused in
+                            * stream order. mif_match_sharded_sync and _destroy wait for the end of the last
+                            * search on whichever stream it ran. */
 } mif_shard_io;
 
 /* One search: io[i] belongs to local rank i. nq, dim and ld must be the same on every rank of the

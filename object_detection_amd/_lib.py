@@ -31,6 +31,7 @@ SYMBOLS = [
     ("mif_sift_enqueue_pyramid", C.c_int, [_P, _P, C.c_int]),
     ("mif_sift_enqueue_features", C.c_int, [_P, C.c_int]),
     ("mif_sift_snapshot_frame", C.c_int, [_P, C.c_int, _P, _P]),
+    ("mif_sift_pack_results", C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int]),
     ("mif_stream_wait_stream", C.c_int, [C.c_int, _P, _P]),
     ("mif_stream_create_masked", C.c_int, [C.c_int, C.POINTER(C.c_uint32), C.c_int, C.POINTER(_P)]),
     ("mif_stream_destroy", C.c_int, [C.c_int, _P]),
@@ -66,6 +67,8 @@ SYMBOLS = [
     ("mif_surf_stream", _P, [_P]),
     ("mif_surf_device_results", C.c_int, [_P] + [C.POINTER(_P)] * 6),
     ("mif_surf_copy_integral", C.c_int, [_P, _P]),
+    ("mif_surf_set_timing", C.c_int, [_P, C.c_int]),
+    ("mif_surf_stage_times", C.c_int, [_P, _P]),
     ("mif_surf_layer_info", C.c_int, [_P, C.c_int, _PI, _PI, _PI, _PI]),
     ("mif_surf_copy_layer", C.c_int, [_P, C.c_int, _P, _P]),
     ("mif_match_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),

@@ -1,5 +1,7 @@
-// ccl_surf:: host shims over the C ABI (see ccl_surf.h). One process-global
-// pipeline like the reference's surf_items::alg_surf (ccl_surf.cpp:766).
+// ccl_surf:: host shims over the C ABI (see ccl_surf.h). Process-global state like the reference's
+// surf_items::alg_surf (ccl_surf.cpp:766), which is rebuilt when the image grows (ccl_surf.cpp:806-810).
+// Here the last few geometries keep their pipelines, so that a caller that alternates between two
+// images (the -m demo) builds each once.
 #include "ccl_surf.h"
 
 #include <cstring>
@@ -12,13 +14,31 @@ static_assert(sizeof(ccl_surf::Ipoint) == sizeof(mif_ipoint), "Ipoint must match
 
 namespace
 {
-    struct Global
+    struct Slot
     {
         mif_surf* handle = nullptr;
-        int rows = 0, cols = 0, channels = 0, device = 0;
-        bool initialized = false;
+        int rows = 0, cols = 0, channels = 0;
+        unsigned long used = 0;
+    };
+    constexpr int kSlots = 4;
+
+    struct Global
+    {
+        Slot slot[kSlots];
+        unsigned long clock = 0;
+        mif_surf* handle = nullptr;          // the pipeline of the last call (one of the slots')
+        int device = 0;
+        bool initialized = false, quiet = false;
         float last_ms = 0.0f;
-        ~Global() { mif_surf_destroy(handle); }
+        void drop_all()
+        {
+            for (Slot& sl : slot) {
+                mif_surf_destroy(sl.handle);
+                sl = Slot();
+            }
+            handle = nullptr;
+        }
+        ~Global() { drop_all(); }
     };
 
     Global& g()
@@ -64,21 +84,32 @@ namespace ccl_surf
             std::cerr << "Some err on main surf loop, FIXME!!" << std::endl;
             return {};
         }
-        if (G.handle == nullptr || G.rows != img.rows || G.cols != img.cols || G.channels != img.channels()) {
-            mif_surf_destroy(G.handle);
+        Slot* hit = nullptr;
+        Slot* victim = &G.slot[0];
+        for (Slot& sl : G.slot) {
+            if (sl.handle && sl.rows == img.rows && sl.cols == img.cols && sl.channels == img.channels()) hit = &sl;
+            if (!sl.handle || (victim->handle && sl.used < victim->used)) victim = &sl;
+        }
+        if (!hit) {
+            mif_surf_destroy(victim->handle);
+            *victim = Slot();
             G.handle = nullptr;
-            if (mif_surf_create(G.device, img.cols, img.rows, img.channels(), &G.handle) != MIF_OK) {
+            if (mif_surf_create(G.device, img.cols, img.rows, img.channels(), &victim->handle) != MIF_OK) {
                 std::cerr << "Some err on main surf loop, FIXME!! " << mif_last_error() << std::endl;
                 return {};
             }
-            G.rows = img.rows; G.cols = img.cols; G.channels = img.channels();
+            victim->rows = img.rows; victim->cols = img.cols; victim->channels = img.channels();
+            mif_surf_set_timing(victim->handle, 1);
+            hit = victim;
         }
+        hit->used = ++G.clock;
+        G.handle = hit->handle;
         IpVec pts((size_t)mif_surf_capacity(G.handle));
         int n = 0;
         const int rc = mif_surf_run(G.handle, img.data, reinterpret_cast<mif_ipoint*>(pts.data()), (int)pts.size(), &n,
                                     nullptr, &G.last_ms);
         if (rc != MIF_OK || n == 0) {
-            std::cerr << "Some err on main surf loop, FIXME!!" << std::endl;
+            if (!G.quiet || rc != MIF_OK) std::cerr << "Some err on main surf loop, FIXME!!" << std::endl;
             return {};
         }
         pts.resize((size_t)n);
@@ -93,7 +124,14 @@ namespace ccl_surf
             std::cerr << "Couldn't open:\t" << file << " ,fixme!!!" << std::endl;
             return false;
         }
+        // one record per stage of the last call (the reference: one per task, ccl_surf.cpp:859-878)
         ofs << "surf_frame_gpu_ms," << g().last_ms << std::endl;
+        float ms[MIF_SURF_STAGES];
+        if (g().handle && mif_surf_stage_times(g().handle, ms) == MIF_OK) {
+            static const char* names[MIF_SURF_STAGES] = {"integral_image", "hessian_det", "non_max_supression",
+                                                         "getOrientation", "createDescriptors"};
+            for (int i = 0; i < MIF_SURF_STAGES; i++) ofs << names[i] << "_gpu_ms," << ms[i] << std::endl;
+        }
         return true;
     }
 
@@ -101,8 +139,9 @@ namespace ccl_surf
     {
         Global& G = g();
         if (device == G.device) return;
-        mif_surf_destroy(G.handle);
-        G.handle = nullptr;
+        G.drop_all();
         G.device = device;
     }
+
+    void set_quiet(bool quiet) { g().quiet = quiet; }
 }

@@ -41,8 +41,10 @@ namespace ccl_surf
     // interest point is found (ccl_surf.cpp:791-795, 813-817).
     IpVec run(const mif::Image& img, bool use_images_in_kernelfunc = false);
 
-    // ccl_surf.h:32. Writes the GPU time of the last frame to `file`.
+    // ccl_surf.h:32. Writes the GPU time of the last frame and of each of its stages to `file`.
     bool write_task_times_to_file(const std::string file);
 
     void set_device(int device);
+    // true: no progress or "no point found" lines (timing loops); errors are still reported.
+    void set_quiet(bool quiet);
 }

@@ -1,6 +1,7 @@
 #include "kpmatch.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -15,22 +16,44 @@ namespace fmatches
     namespace
     {
         int g_device = 0;
+        bool g_quiet = false;
+
+        // The matcher workspace is kept from call to call and grows with the largest request seen
+        // (the reference builds a cv::FlannBasedMatcher per call, common/kpmatch.h:174).
+        struct MatcherCache
+        {
+            mif_matcher* m = nullptr;
+            int device = -1, max_q = 0, max_d = 0;
+            ~MatcherCache() { mif_match_destroy(m); }
+        };
+
+        double ms_since(const std::chrono::steady_clock::time_point& t0)
+        {
+            return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
 
         // exact 2-NN of every query row on the GPU
         bool gpu_top2(const std::vector<float>& q, int nq, const std::vector<float>& db, int nd, int dim,
                       std::vector<int>& idx2, std::vector<float>& dist2)
         {
+            static MatcherCache cache;
             idx2.assign((size_t)nq * 2, -1);
             dist2.assign((size_t)nq * 2, std::numeric_limits<float>::infinity());
             if (nq == 0) return true;
-            mif_matcher* m = nullptr;
-            if (mif_match_create(g_device, std::max(nq, 1), std::max(nd, 1), &m) != MIF_OK) {
-                std::cerr << "matcher: " << mif_last_error() << std::endl;
-                return false;
+            if (!cache.m || cache.device != g_device || cache.max_q < nq || cache.max_d < nd) {
+                mif_match_destroy(cache.m);
+                cache.m = nullptr;
+                cache.max_q = std::max(cache.max_q, std::max(nq, 1));
+                cache.max_d = std::max(cache.max_d, std::max(nd, 1));
+                cache.device = g_device;
+                if (mif_match_create(g_device, cache.max_q, cache.max_d, &cache.m) != MIF_OK) {
+                    std::cerr << "matcher: " << mif_last_error() << std::endl;
+                    cache.max_q = cache.max_d = 0;
+                    return false;
+                }
             }
-            const int rc = mif_match_top2(m, q.data(), nq, db.data(), nd, dim, dim, idx2.data(), dist2.data());
+            const int rc = mif_match_top2(cache.m, q.data(), nq, db.data(), nd, dim, dim, idx2.data(), dist2.data());
             if (rc != MIF_OK) std::cerr << "matcher: " << mif_last_error() << std::endl;
-            mif_match_destroy(m);
             return rc == MIF_OK;
         }
 
@@ -139,6 +162,7 @@ namespace fmatches
                            const std::vector<Point2f>& pts_scene, bool up_scale)
         {
             // common/kpmatch.h:223-243
+            const auto t0 = std::chrono::steady_clock::now();
             std::vector<Point2f> obj, scene;
             for (const DMatch& m : rep.good_matches) {
                 obj.push_back(pts_object[m.queryIdx]);
@@ -148,6 +172,7 @@ namespace fmatches
             rep.has_homography = findHomographyRansac(obj, scene, rep.H, &mask);
             if (!rep.has_homography) {
                 std::cerr << "Couldn't findHomography ... fixme!! " << std::endl;
+                rep.homography_ms = ms_since(t0);
                 return;
             }
             rep.inliers = (int)std::count(mask.begin(), mask.end(), (char)1);
@@ -155,10 +180,12 @@ namespace fmatches
             const float cols = img_object.cols * f, rows = img_object.rows * f;
             const Point2f corners[4] = {{0, 0}, {cols, 0}, {cols, rows}, {0, rows}};
             for (int i = 0; i < 4; i++) rep.scene_corners[i] = perspectiveTransform(corners[i], rep.H);
+            rep.homography_ms = ms_since(t0);
         }
     }
 
     void set_device(int device) { g_device = device; }
+    void set_quiet(bool quiet) { g_quiet = quiet; }
 
     void ConvertToKeyPoint(const std::vector<sift_feat>& kp_in, std::vector<Point2f>& pts, std::vector<float>& desc)
     {
@@ -233,6 +260,7 @@ namespace fmatches
                                      const bool up_scale)
     {
         MatchReport rep;
+        const auto t0 = std::chrono::steady_clock::now();
         std::vector<Point2f> pts_object, pts_scene;
         std::vector<float> desc_object, desc_scene;
         ConvertToKeyPoint(kp_object, pts_object, desc_object);
@@ -247,12 +275,15 @@ namespace fmatches
             if (dist < rep.min_dist) rep.min_dist = dist;
             if (dist > rep.max_dist) rep.max_dist = dist;
         }
-        std::printf("-- Max dist : %f \n", rep.max_dist);
-        std::printf("-- Min dist : %f \n", rep.min_dist);
+        if (!g_quiet) {
+            std::printf("-- Max dist : %f \n", rep.max_dist);
+            std::printf("-- Min dist : %f \n", rep.min_dist);
+        }
         for (int i = 0; i < nq; i++)
             if (idx2[2 * i] >= 0 && dist2[2 * i] <= std::max(2.5 * rep.min_dist, 0.35))
                 rep.good_matches.push_back(DMatch{i, idx2[2 * i], dist2[2 * i]});
-        std::cout << "Good matches: " << rep.good_matches.size() << std::endl;
+        if (!g_quiet) std::cout << "Good matches: " << rep.good_matches.size() << std::endl;
+        rep.match_ms = ms_since(t0);
         finish_report(rep, img_object, pts_object, pts_scene, up_scale);
         return rep;
     }
@@ -262,6 +293,7 @@ namespace fmatches
                                      const bool up_scale)
     {
         MatchReport rep;
+        const auto t0 = std::chrono::steady_clock::now();
         std::vector<Point2f> pts_object, pts_scene;
         std::vector<float> desc_object, desc_scene;
         ConvertToKeyPoint(kp_object, pts_object, desc_object);
@@ -275,17 +307,30 @@ namespace fmatches
         for (int i = 0; i < nq; i++)
             if (idx2[2 * i] >= 0 && dist2[2 * i] < ratio_thresh * dist2[2 * i + 1])
                 rep.good_matches.push_back(DMatch{i, idx2[2 * i], dist2[2 * i]});
-        std::cout << "Found stable matches:\t" << rep.good_matches.size() << std::endl;
+        if (!g_quiet) std::cout << "Found stable matches:\t" << rep.good_matches.size() << std::endl;
+        rep.match_ms = ms_since(t0);
         if (!rep.good_matches.empty()) finish_report(rep, img_object, pts_object, pts_scene, up_scale);
         return rep;
     }
 
     bool write_report_json(const std::string& path, const MatchReport& rep)
     {
+        return write_report_json(path, rep, Timing());
+    }
+
+    bool write_report_json(const std::string& path, const MatchReport& rep, const Timing& tm)
+    {
         std::ofstream out(path);
         if (!out.is_open()) return false;
         out.precision(9);
-        out << "{\n  \"min_dist\": " << rep.min_dist << ", \"max_dist\": " << rep.max_dist << ",\n  \"good_matches\": [";
+        out << "{\n";
+        if (tm.repeats > 0)
+            out << "  \"timing_ms\": {\"repeats\": " << tm.repeats << ", \"extract_object\": " << tm.extract_object
+                << ", \"extract_scene\": " << tm.extract_scene << ", \"convert\": " << tm.convert
+                << ", \"match\": " << tm.match << ", \"homography\": " << tm.homography
+                << ", \"total\": " << tm.total << ", \"total_min\": " << tm.total_min
+                << ", \"feats_object\": " << tm.feats_object << ", \"feats_scene\": " << tm.feats_scene << "},\n";
+        out << "  \"min_dist\": " << rep.min_dist << ", \"max_dist\": " << rep.max_dist << ",\n  \"good_matches\": [";
         for (size_t i = 0; i < rep.good_matches.size(); i++) {
             const DMatch& m = rep.good_matches[i];
             out << (i ? ", " : "") << "[" << m.queryIdx << ", " << m.trainIdx << ", " << m.distance << "]";

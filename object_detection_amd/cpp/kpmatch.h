@@ -80,6 +80,9 @@ namespace fmatches
         double H[9] = { 0 };                 // row-major 3x3, maps object to scene
         int inliers = 0;
         Point2f scene_corners[4] = {};       // object corners (0,0) (w,0) (w,h) (0,h) mapped into the scene
+        // host wall-clock of the two steps of the call that made this report
+        double match_ms = 0;                 // descriptor matrices, GPU search (host buffers in, results out), filter
+        double homography_ms = 0;            // RANSAC + DLT + corner projection
     };
 
     // SIFT overload of Plot_Img_Matches_ocv (common/kpmatch.h:162-268) without the drawing: nearest
@@ -108,4 +111,17 @@ namespace fmatches
     bool write_report_json(const std::string& path, const MatchReport& report);
 
     void set_device(int device);
+    // true: the "-- Max dist" / "Good matches:" lines of the reference are not printed (timing loops)
+    void set_quiet(bool quiet);
+
+    // Wall-clock summary of a demo's repeat loop (-r N), written into the JSON report.
+    struct Timing
+    {
+        int repeats = 0;
+        // means over the repeats, host to host, in ms
+        double extract_object = 0, extract_scene = 0, convert = 0, match = 0, homography = 0, total = 0;
+        double total_min = 0;                // fastest repeat
+        size_t feats_object = 0, feats_scene = 0;
+    };
+    bool write_report_json(const std::string& path, const MatchReport& report, const Timing& timing);
 }

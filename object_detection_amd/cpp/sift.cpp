@@ -1,6 +1,7 @@
-// SIFT:: host shims over the C ABI (see sift.h). One process-global pipeline,
-// rebuilt when the image geometry changes, like the reference's
-// `static std::unique_ptr<sift_algorithm> sift` (SIFT/sift.cpp:1992, 2148-2189).
+// SIFT:: host shims over the C ABI (see sift.h). Process-global state like the reference's
+// `static std::unique_ptr<sift_algorithm> sift` (SIFT/sift.cpp:1992, 2148-2189), which is rebuilt
+// whenever the image geometry changes. Here the last few geometries keep their pipelines, so that a
+// caller that alternates between two images (the -m demo: object, scene, object, ...) builds each once.
 #include "sift.h"
 
 #include <cstdio>
@@ -12,15 +13,35 @@
 
 namespace
 {
-    struct Global
+    struct Slot
     {
         mif_sift* handle = nullptr;
-        int width = 0, height = 0, depth = 0, device = 0;
+        int width = 0, height = 0, depth = 0;
+        bool up = false;
+        unsigned long used = 0;
+    };
+    constexpr int kSlots = 4;
+
+    struct Global
+    {
+        Slot slot[kSlots];
+        unsigned long clock = 0;
+        mif_sift* handle = nullptr;          // the pipeline of the last call (one of the slots')
+        int device = 0;
         std::vector<float> kp, ori, desc, probe;
         // per-stage GPU times of every extraction so far, [call][octave][stage] (the reference keeps one
         // record per task call, clDriver.h:1172-1247)
         std::vector<float> history;
-        ~Global() { mif_sift_destroy(handle); }
+        bool quiet = false;                  // no progress lines (timing loops)
+        void drop_all()
+        {
+            for (Slot& sl : slot) {
+                mif_sift_destroy(sl.handle);
+                sl = Slot();
+            }
+            handle = nullptr;
+        }
+        ~Global() { drop_all(); }
     };
 
     Global& g()
@@ -39,23 +60,35 @@ namespace
             return MIF_ERR_INVALID_ARGUMENT;
         }
         Global& G = g();
-        if (G.handle == nullptr || width != G.width || height != G.height || depth != G.depth) {
-            std::cout << "Initialize ..." << std::endl;
-            mif_sift_destroy(G.handle);
+        Slot* hit = nullptr;
+        Slot* victim = &G.slot[0];
+        for (Slot& sl : G.slot) {
+            if (sl.handle && sl.width == width && sl.height == height && sl.depth == depth && sl.up == up_scale) hit = &sl;
+            if (!sl.handle || (victim->handle && sl.used < victim->used)) victim = &sl;
+        }
+        if (!hit) {
+            if (!G.quiet) std::cout << "Initialize ..." << std::endl;
+            mif_sift_destroy(victim->handle);
+            *victim = Slot();
             G.handle = nullptr;
-            const int rc = mif_sift_create(G.device, width, height, depth, up_scale ? 1 : 0, &G.handle);
+            const int rc = mif_sift_create(G.device, width, height, depth, up_scale ? 1 : 0, &victim->handle);
             if (rc != MIF_OK) {
                 std::cerr << "SIFT: " << mif_last_error() << std::endl;
                 return rc;
             }
-            G.width = width; G.height = height; G.depth = depth;
-            const size_t cap = (size_t)mif_sift_capacity(G.handle);
+            victim->width = width; victim->height = height; victim->depth = depth; victim->up = up_scale;
+            mif_sift_set_timing(victim->handle, 1);
+            hit = victim;
+        }
+        hit->used = ++G.clock;
+        G.handle = hit->handle;
+        const size_t cap = (size_t)mif_sift_capacity(G.handle);
+        if (G.kp.size() < cap * 4) {
             G.kp.resize(cap * 4);
             G.ori.resize(cap);
             G.desc.resize(cap * MIF_SIFT_DESC_DIM);
-            mif_sift_set_timing(G.handle, 1);
         }
-        std::cout << "Execute ..." << std::endl;
+        if (!G.quiet) std::cout << "Execute ..." << std::endl;
         return MIF_OK;
     }
 
@@ -94,9 +127,11 @@ namespace
             descriptors->insert(descriptors->end(), G.desc.begin(), G.desc.begin() + row * MIF_SIFT_DESC_DIM);
             orientations->insert(orientations->end(), G.ori.begin(), G.ori.begin() + row);
         }
-        std::cout << "--------------------------------------------------------" << std::endl;
-        std::cout << "Elapsed_time_ms," << ms << std::endl;
-        std::cout << "--------------------------------------------------------" << std::endl;
+        if (!G.quiet) {
+            std::cout << "--------------------------------------------------------" << std::endl;
+            std::cout << "Elapsed_time_ms," << ms << std::endl;
+            std::cout << "--------------------------------------------------------" << std::endl;
+        }
         return MIF_OK;
     }
 
@@ -221,8 +256,9 @@ namespace SIFT
     {
         Global& G = g();
         if (device == G.device) return;
-        mif_sift_destroy(G.handle);
-        G.handle = nullptr;
+        G.drop_all();
         G.device = device;
     }
+
+    void set_quiet(bool quiet) { g().quiet = quiet; }
 }

@@ -73,6 +73,9 @@ namespace SIFT
     std::vector<float> test_ColorToGray_Resize(float offload, const unsigned char* image, int width, int height,
                                                int color_depth, float ratio_x, float ratio_y);
 
-    // GPU used by the calls above (default 0); changing it drops the cached pipeline.
+    // GPU used by the calls above (default 0); changing it drops the cached pipelines.
     void set_device(int device);
+    // true: the calls above print none of the reference's progress lines ("Initialize ...", "Execute ...",
+    // "Elapsed_time_ms,"): for timing loops. Errors are still reported.
+    void set_quiet(bool quiet);
 }

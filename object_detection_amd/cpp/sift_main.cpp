@@ -1,5 +1,7 @@
 // demo_coopcl_sift: the command line of the reference's SIFT demo (SIFT/main.cpp) on the GPU path.
-//   -m object.pgm scene.pgm -f x   extract both, match, homography; report to stdout (+ -o report.json)
+//   -m object.pgm scene.pgm -f x   extract both, match, homography; report to stdout (+ -o report.json);
+//                                  -r N repeats the whole sequence N more times without output and adds
+//                                  the mean host-to-host milliseconds of every step to the report
 //   -v frames -f x [-b N] [-g G]   per-frame extraction and matching against the previous frame;
 //                                  frames = "file.raw:WxHxC" or a printf pattern of PGM/PPM files;
 //                                  -b N sends batches of N frames through the GPU-resident pipeline;
@@ -30,7 +32,7 @@ static std::string option(int argc, char** argv, const std::string& name)
 
 // SIFT/main.cpp:176-206
 static int call_feature_match_demo(const std::string& object_path, const std::string& scene_path, float offload,
-                                   const std::string& report_path)
+                                   const std::string& report_path, int repeats)
 {
     auto frame_object = mif::imread(object_path, true);
     auto frame_scene = mif::imread(scene_path, true);
@@ -61,7 +63,57 @@ static int call_feature_match_demo(const std::string& object_path, const std::st
             std::cout << "corner" << i << ":\t" << report.scene_corners[i].x << "\t" << report.scene_corners[i].y
                       << std::endl;
     }
-    if (!report_path.empty()) fmatches::write_report_json(report_path, report);
+    // -r N: the same sequence N more times (pipelines and matcher workspace exist by now), timed step by
+    // step with the host's clock: pixels in host memory -> features, matches, homography in host memory
+    fmatches::Timing tm;
+    if (repeats > 0) {
+        using clock = std::chrono::steady_clock;
+        auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        SIFT::set_quiet(true);
+        fmatches::set_quiet(true);
+        tm.total_min = 1e30;
+        for (int r = 0; r < repeats; r++) {
+            std::vector<SIFT::sfeature> fo, fs;
+            std::vector<float> dso, dss, oo, os;
+            const auto t0 = clock::now();
+            err = SIFT::extract_features(elapsed_time, offload, frame_object.data, frame_object.cols, frame_object.rows,
+                                         frame_object.channels(), fo, dso, oo, up_scale);
+            const auto t1 = clock::now();
+            if (err == 0)
+                err = SIFT::extract_features(elapsed_time, offload, frame_scene.data, frame_scene.cols, frame_scene.rows,
+                                             frame_scene.channels(), fs, dss, os, up_scale);
+            const auto t2 = clock::now();
+            if (err != 0) return err;
+            std::vector<fmatches::sift_feat> ko, ks;
+            fmatches::ConvertToSift_feat<SIFT::sfeature>(fo, oo, dso, ko);
+            fmatches::ConvertToSift_feat<SIFT::sfeature>(fs, os, dss, ks);
+            const auto t3 = clock::now();
+            const auto rep = fmatches::Plot_Img_Matches_ocv(frame_object, frame_scene, ko, ks, up_scale);
+            const auto t4 = clock::now();
+            if (rep.good_matches.size() != report.good_matches.size() || fo.size() != feats_object.size()) {
+                std::cerr << "repeat " << r << " differs from the first run" << std::endl;
+                return -1;
+            }
+            tm.extract_object += ms(t0, t1);
+            tm.extract_scene += ms(t1, t2);
+            tm.convert += ms(t2, t3);
+            tm.match += rep.match_ms;
+            tm.homography += rep.homography_ms;
+            tm.total += ms(t0, t4);
+            tm.total_min = std::min(tm.total_min, ms(t0, t4));
+        }
+        SIFT::set_quiet(false);
+        fmatches::set_quiet(false);
+        tm.repeats = repeats;
+        for (double* v : {&tm.extract_object, &tm.extract_scene, &tm.convert, &tm.match, &tm.homography, &tm.total})
+            *v /= repeats;
+        tm.feats_object = feats_object.size();
+        tm.feats_scene = feats_scene.size();
+        std::cout << "Repeats:\t" << repeats << "\tmean total_ms:\t" << tm.total << "\textract:\t"
+                  << tm.extract_object + tm.extract_scene << "\tmatch:\t" << tm.match << "\thomography:\t"
+                  << tm.homography << std::endl;
+    }
+    if (!report_path.empty()) fmatches::write_report_json(report_path, report, tm);
     return 0;
 }
 
@@ -260,6 +312,7 @@ int main(int argc, char** argv)
         std::cerr << "Error opening video stream or file:\t(camera input is not available in this build)" << std::endl;
         return -1;
     } else if (args.app_mode == "-m")
-        return call_feature_match_demo(args.img_path_a, args.img_path_b, args.offload, report);
+        return call_feature_match_demo(args.img_path_a, args.img_path_b, args.offload, report,
+                                       std::max(0, std::atoi(option(argc, argv, "-r").c_str())));
     return 0;
 }

@@ -1,8 +1,12 @@
 // demo_coopcl_Surf: the command line of the reference's SURF demo (SURF/coopcl_surf/main.cpp) on the GPU path.
-//   -m object.pgm scene.pgm -f x   extract both, ratio-test matching, homography (+ -o report.json)
+//   -m object.pgm scene.pgm -f x   extract both, ratio-test matching, homography (+ -o report.json);
+//                                  -r N repeats the whole sequence N more times without output and adds
+//                                  the mean host-to-host milliseconds of every step to the report
 //   -v frames -f x                 per-frame extraction; frames = "file.raw:WxHxC" or a printf pattern
 //   -i image -f x                  extract one image, print the point count
+#include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <iostream>
 
@@ -40,7 +44,7 @@ static void copy_ipoints(const ccl_surf::IpVec& src, std::vector<fmatches::Ipoin
 
 // SURF/coopcl_surf/main.cpp:141-182
 static int call_feature_match_demo(const std::string& object_path, const std::string& scene_path,
-                                   const std::string& report_path)
+                                   const std::string& report_path, int repeats)
 {
     auto frame_object = mif::imread(object_path, true);
     auto frame_scene = mif::imread(scene_path, true);
@@ -60,7 +64,51 @@ static int call_feature_match_demo(const std::string& object_path, const std::st
             std::cout << "corner" << i << ":\t" << report.scene_corners[i].x << "\t" << report.scene_corners[i].y
                       << std::endl;
     }
-    if (!report_path.empty()) fmatches::write_report_json(report_path, report);
+    // -r N: the same sequence N more times (pipelines and matcher workspace exist by now), timed step by
+    // step with the host's clock: pixels in host memory -> points, matches, homography in host memory
+    fmatches::Timing tm;
+    if (repeats > 0) {
+        using clock = std::chrono::steady_clock;
+        auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        ccl_surf::set_quiet(true);
+        fmatches::set_quiet(true);
+        tm.total_min = 1e30;
+        for (int r = 0; r < repeats; r++) {
+            const auto t0 = clock::now();
+            const auto io = ccl_surf::run(frame_object);
+            const auto t1 = clock::now();
+            const auto is = ccl_surf::run(frame_scene);
+            const auto t2 = clock::now();
+            std::vector<fmatches::Ipoint> fo, fs;
+            copy_ipoints(io, fo);
+            copy_ipoints(is, fs);
+            const auto t3 = clock::now();
+            const auto rep = fmatches::Plot_Img_Matches_ocv(frame_object, frame_scene, fo, fs);
+            const auto t4 = clock::now();
+            if (rep.good_matches.size() != report.good_matches.size() || fo.size() != feats_object.size()) {
+                std::cerr << "repeat " << r << " differs from the first run" << std::endl;
+                return -1;
+            }
+            tm.extract_object += ms(t0, t1);
+            tm.extract_scene += ms(t1, t2);
+            tm.convert += ms(t2, t3);
+            tm.match += rep.match_ms;
+            tm.homography += rep.homography_ms;
+            tm.total += ms(t0, t4);
+            tm.total_min = std::min(tm.total_min, ms(t0, t4));
+        }
+        ccl_surf::set_quiet(false);
+        fmatches::set_quiet(false);
+        tm.repeats = repeats;
+        for (double* v : {&tm.extract_object, &tm.extract_scene, &tm.convert, &tm.match, &tm.homography, &tm.total})
+            *v /= repeats;
+        tm.feats_object = feats_object.size();
+        tm.feats_scene = feats_scene.size();
+        std::cout << "Repeats:\t" << repeats << "\tmean total_ms:\t" << tm.total << "\textract:\t"
+                  << tm.extract_object + tm.extract_scene << "\tmatch:\t" << tm.match << "\thomography:\t"
+                  << tm.homography << std::endl;
+    }
+    if (!report_path.empty()) fmatches::write_report_json(report_path, report, tm);
     return 0;
 }
 
@@ -117,6 +165,8 @@ int main(int argc, char** argv)
         std::cerr << "Error opening video stream or file:\t(camera input is not available in this build)" << std::endl;
         return -1;
     }
-    if (args.app_mode == "-m") return call_feature_match_demo(args.img_path_a, args.img_path_b, report);
+    if (args.app_mode == "-m")
+        return call_feature_match_demo(args.img_path_a, args.img_path_b, report,
+                                       std::max(0, std::atoi(option(argc, argv, "-r").c_str())));
     return 0;
 }

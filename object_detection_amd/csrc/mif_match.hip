@@ -1990,10 +1990,12 @@ static __device__ __align__(256) unsigned char scratch[kNaBytes];
 
 constexpr int kNaDevices = 64;
 unsigned char* g_na_ptr[kNaDevices] = {};       // device address of `scratch` on every GPU seen so far
+int g_na_blocks[kNaDevices] = {};               // grid of the search kernel there: two blocks per compute unit
 std::mutex g_na_mutex;
 
-// Device address of this GPU's copy of the array; `device` is current.
-int noalloc_scratch(int device, unsigned char** out)
+// Device address of this GPU's copy of the array and the search kernel's grid; `device` is current.
+// Both are asked for on the first call on a device and kept, so that later calls query nothing.
+int noalloc_scratch(int device, unsigned char** out, int* blocks)
 {
     std::lock_guard<std::mutex> lock(g_na_mutex);
     if (!g_na_ptr[device]) {
@@ -2004,9 +2006,14 @@ int noalloc_scratch(int device, unsigned char** out)
                            hipGetErrorString(e));
             return MIF_ERR_HIP;
         }
+        int cus = 0;
+        g_na_blocks[device] = 512;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+            g_na_blocks[device] = 2 * cus;
         g_na_ptr[device] = static_cast<unsigned char*>(p);
     }
     *out = g_na_ptr[device];
+    *blocks = g_na_blocks[device];
     return MIF_OK;
 }
 
@@ -2042,7 +2049,8 @@ int mif_match_top2_device_noalloc(int device, const float* d_q, int nq, const fl
     mif::DeviceGuard guard(device);
     if (!guard.ok) { mif::set_error("mif_match_top2_device_noalloc: cannot select device %d", device); return MIF_ERR_HIP; }
     unsigned char* base = nullptr;
-    const int rc = noalloc_scratch(device, &base);
+    int blocks = 512;
+    const int rc = noalloc_scratch(device, &base, &blocks);
     if (rc != MIF_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     mif_match_pair* tbl = reinterpret_cast<mif_match_pair*>(base + kNaOffTable);
@@ -2059,10 +2067,6 @@ int mif_match_top2_device_noalloc(int device, const float* d_q, int nq, const fl
     const bool vec_db = (ld % 4) == 0 && (reinterpret_cast<uintptr_t>(d_db) & 15u) == 0;
     const bool vec_q = (ld % 4) == 0 && (reinterpret_cast<uintptr_t>(d_q) & 15u) == 0;
     const bool vec = vec_db && vec_q;
-    int blocks = 512;
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
-        blocks = 2 * cus;
     if (nd > 0) {
         // the counters of the last call are stale: they start from zero; norms and partial winners are
         // written before they are read for every row and split this call uses

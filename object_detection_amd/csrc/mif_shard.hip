@@ -150,6 +150,7 @@ struct Shard {
     float* recv = nullptr;              // [nranks][max_q][6]
     hipEvent_t packed = nullptr;        // device-copy exchange: the message is complete
     hipEvent_t taken = nullptr;         // device-copy exchange: this shard has copied every message
+    hipEvent_t done = nullptr;          // end of the shard's part of the last search, on whichever stream it ran
 };
 
 } // namespace
@@ -168,6 +169,9 @@ void free_sharded(mif_match_sharded* h)
     const Rccl* R = h->device_copies ? nullptr : rccl();
     for (Shard& sh : h->s) {
         mif::DeviceGuard guard(sh.device);
+        // the last search may have run on a stream of the caller's (mif_shard_io.stream): its end is an
+        // event, which stays valid whatever happened to that stream since
+        if (sh.done && h->searched) (void)hipEventSynchronize(sh.done);
         if (sh.stream) (void)hipStreamSynchronize(sh.stream);
         if (sh.comm && R) (void)R->CommDestroy(sh.comm);
         if (sh.matcher) (void)mif_match_destroy(sh.matcher);
@@ -175,6 +179,7 @@ void free_sharded(mif_match_sharded* h)
         (void)hipFree(sh.send); (void)hipFree(sh.recv);
         if (sh.packed) (void)hipEventDestroy(sh.packed);
         if (sh.taken) (void)hipEventDestroy(sh.taken);
+        if (sh.done) (void)hipEventDestroy(sh.done);
         if (sh.stream) (void)hipStreamDestroy(sh.stream);
     }
 }
@@ -246,6 +251,7 @@ int mif_match_sharded_create(const int* devices, int nlocal, int first_rank, int
         if (e == hipSuccess) e = hipMalloc(&sh.recv, (size_t)nranks * Q * kMsgFloats * sizeof(float));
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sh.packed, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sh.taken, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sh.done, hipEventDisableTiming);
         if (e != hipSuccess) {
             mif::set_error("mif_match_sharded_create: %s", hipGetErrorString(e));
             return fail(MIF_ERR_HIP);
@@ -331,6 +337,12 @@ int mif_match_sharded_search(mif_match_sharded* h, const mif_shard_io* io, int n
             return MIF_ERR_INVALID_ARGUMENT;
         }
     }
+    // everything the local searches would refuse is refused here, before the first shard enqueues:
+    // a rank that returned between its enqueue and the collective would leave the other ranks waiting
+    if (dim < 1 || dim > 128 || ld < dim) {
+        mif::set_error("mif_match_sharded_search: dim must be 1..128 and ld >= dim (got dim %d, ld %d)", dim, ld);
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
     if (nq == 0) return MIF_OK;
     const Rccl* R = nullptr;
     if (!h->device_copies) {
@@ -395,6 +407,7 @@ int mif_match_sharded_search(mif_match_sharded* h, const mif_shard_io* io, int n
         hipLaunchKernelGGL(k_shard_merge, dim3((nq + 255) / 256), dim3(256), 0, st, (const float*)sh.recv, h->nranks, nq,
                            io[i].d_idx2, io[i].d_dist2);
         MIF_HIP(hipGetLastError());
+        MIF_HIP(hipEventRecord(sh.done, st));
     }
     h->searched = true;
     return MIF_OK;
@@ -405,6 +418,7 @@ int mif_match_sharded_sync(mif_match_sharded* h)
     if (!h) return MIF_ERR_INVALID_ARGUMENT;
     for (Shard& sh : h->s) {
         mif::DeviceGuard guard(sh.device);
+        if (h->searched) MIF_HIP(hipEventSynchronize(sh.done));     // the last search, wherever it ran
         MIF_HIP(hipStreamSynchronize(sh.stream));
     }
     return MIF_OK;

@@ -1652,6 +1652,53 @@ __global__ void k_finish(int* counts, int nframes, int want_desc)
     }
 }
 
+// Readback of a whole batch (sift.cpp:1889-1911 appends features(), orientations() and descriptors()
+// octave by octave; a frame's rows are already packed like that at row frame * cap). First row of every
+// frame in the packed arrays: exclusive scan of the frames' totals, cut at max_rows.
+// offsets[f] = first row of frame f, offsets[nframes] = rows packed, offsets[nframes + 1] = rows the
+// batch holds. One block of 1024 threads (a batch has at most 1024 frames).
+__global__ __launch_bounds__(1024) void k_pack_offsets(const int* __restrict__ counts, int nframes, int max_rows,
+                                                       int* __restrict__ offsets)
+{
+    __shared__ int s_scan[1024];
+    const int f = threadIdx.x;
+    const int n = f < nframes ? counts[(size_t)f * CNT_WORDS + CNT_TOTAL] : 0;
+    s_scan[f] = n;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int add = f >= d ? s_scan[f - d] : 0;
+        __syncthreads();
+        s_scan[f] += add;
+        __syncthreads();
+    }
+    const int incl = s_scan[f];
+    if (f < nframes) offsets[f] = min(incl - n, max_rows);
+    if (f == nframes - 1) {
+        offsets[nframes] = min(incl, max_rows);
+        offsets[nframes + 1] = incl;
+    }
+}
+
+// grid (blocks per frame, frames): the rows [offsets[f], offsets[f + 1]) of the packed arrays are the
+// first rows of frame f's lists. 16-byte moves; a descriptor row is 32 of them.
+__global__ __launch_bounds__(256) void k_pack_rows(const float4* __restrict__ kp, const float* __restrict__ orient,
+                                                   const float4* __restrict__ desc, int cap,
+                                                   const int* __restrict__ offsets, float4* __restrict__ out_kp,
+                                                   float* __restrict__ out_orient, float4* __restrict__ out_desc)
+{
+    const int f = blockIdx.y;
+    const int first = offsets[f];
+    const int n = offsets[f + 1] - first;
+    const size_t src = (size_t)f * cap;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (int i = tid; i < n; i += stride) {
+        out_kp[first + i] = kp[src + i];
+        if (out_orient) out_orient[first + i] = orient[src + i];
+    }
+    if (out_desc)
+        for (int i = tid; i < n * 32; i += stride) out_desc[(size_t)first * 32 + i] = desc[src * 32 + i];
+}
+
 // ------------------------------------------------------------------ host side
 
 struct OctaveBuf {
@@ -1913,6 +1960,7 @@ int enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes, bool split =
         for (int o = 1; o < kOctaves; o++) MIF_HIP(hipStreamWaitEvent(s->aux[o], s->ev_fork, 0));
     }
     int last_l3 = -1;                           // latest octave whose level 3 has been enqueued
+    bool input_recorded = false;                // ev_input marks the end of the first scale space enqueued
     for (int o = 0; o < kOctaves; o++) {
         OctaveBuf& O = s->oct[o];
         const int items = (int)O.items;
@@ -1964,10 +2012,15 @@ int enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes, bool split =
             }
         }
         if (tm) MIF_HIP(hipEventRecord(s->ev_stage[o][2], st));
-        if (o == 0) {                               // nothing after this point reads the caller's pixels
+        if (!input_recorded) {                      // nothing after this point reads the caller's pixels
             MIF_HIP(hipEventRecord(s->ev_input, run));
             s->input_pending = true;
+            input_recorded = true;
         }
+    }
+    if (!input_recorded) {                          // no octave had a pixel: the call read nothing
+        MIF_HIP(hipEventRecord(s->ev_input, st));
+        s->input_pending = true;
     }
     MIF_HIP(hipGetLastError());
     s->pyramid_frames = nf;
@@ -2305,6 +2358,32 @@ int mif_sift_snapshot_frame(mif_sift* s, int frame, float* d_descriptors, int32_
     return MIF_OK;
 }
 
+int mif_sift_pack_results(mif_sift* s, int nframes, float* d_keypoints, float* d_orientations, float* d_descriptors,
+                          int32_t* d_offsets, int max_rows)
+{
+    if (!s || !d_keypoints || !d_offsets || nframes < 1 || nframes > s->batch || max_rows < 0) {
+        mif::set_error("mif_sift_pack_results: bad argument");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    if ((d_orientations == nullptr) != (d_descriptors == nullptr)) {
+        mif::set_error("mif_sift_pack_results: orientations and descriptors must both be given or both be NULL");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    if ((reinterpret_cast<uintptr_t>(d_keypoints) | reinterpret_cast<uintptr_t>(d_descriptors)) & 15u) {
+        mif::set_error("mif_sift_pack_results: keypoints and descriptors must be 16-byte aligned");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(s->device);
+    hipLaunchKernelGGL(k_pack_offsets, dim3(1), dim3(1024), 0, s->stream, (const int*)s->counts, nframes, max_rows,
+                       d_offsets);
+    // a frame holds a few thousand rows of 32 16-byte pieces: 16 blocks of 256 threads walk them
+    hipLaunchKernelGGL(k_pack_rows, dim3(16, nframes), dim3(256), 0, s->stream, (const float4*)s->kp,
+                       (const float*)s->orient, (const float4*)s->desc, s->cap, (const int*)d_offsets,
+                       (float4*)d_keypoints, d_orientations, (float4*)d_descriptors);
+    MIF_HIP(hipGetLastError());
+    return MIF_OK;
+}
+
 int mif_stream_wait_stream(int device, void* waiter, void* signaller)
 {
     // Events are kept per calling thread and device and used in rotation (a call records one and makes
@@ -2339,8 +2418,13 @@ int mif_stream_create_masked(int device, const uint32_t* cu_mask, int words, voi
         mif::set_error("mif_stream_create_masked: bad argument");
         return MIF_ERR_INVALID_ARGUMENT;
     }
-    // one contiguous run of set bits only: a mask of every other bit made the runtime (ROCm 7.2) crash
-    // inside the stream creation
+    // A mask of every other bit (0x55555555 in every word) made the runtime (ROCm 7.2) crash inside the
+    // stream creation. Consecutive bits go to the 8 XCDs in turn, so that mask leaves XCDs 1, 3, 5, 7
+    // without a compute unit; whether the empty XCDs or the gaps were the cause was not established
+    // (the crashing call is not repeated to find out). The guard therefore admits only the family of
+    // masks that has run: one contiguous run of set bits, within the device's compute units, that
+    // leaves every XCD at least one (i.e. at least 8 bits long).
+    constexpr int kXcds = 8;
     int first = -1, last = -1, set = 0;
     for (int i = 0; i < 32 * words; i++)
         if (cu_mask[i / 32] >> (i % 32) & 1u) {
@@ -2352,8 +2436,18 @@ int mif_stream_create_masked(int device, const uint32_t* cu_mask, int words, voi
         mif::set_error("mif_stream_create_masked: the mask must be one contiguous run of set bits");
         return MIF_ERR_INVALID_ARGUMENT;
     }
+    if (set < kXcds) {
+        mif::set_error("mif_stream_create_masked: %d compute units leave some of the %d XCDs without one", set, kXcds);
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
     mif::DeviceGuard guard(device);
     if (!guard.ok) { mif::set_error("mif_stream_create_masked: cannot select device %d", device); return MIF_ERR_HIP; }
+    int ncu = 0;
+    MIF_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+    if (last >= ncu) {
+        mif::set_error("mif_stream_create_masked: bit %d is set, the device has %d compute units", last, ncu);
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
     hipStream_t st = nullptr;
     MIF_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, cu_mask));
     *stream = st;

@@ -767,6 +767,9 @@ struct mif_surf {
     int device = 0, W = 0, H = 0, C = 1, batch = 1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // optional per-stage timing: events at the stage boundaries of a batch
+    bool timing = false, timed = false;
+    hipEvent_t ev_stage[MIF_SURF_STAGES + 1] = {};
     LayerTable tab;
     NmsTable nms;
     size_t pool = 0;
@@ -803,6 +806,8 @@ void surf_free(mif_surf* s)
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    for (hipEvent_t e : s->ev_stage)
+        if (e) (void)hipEventDestroy(e);
     if (s->stream) (void)hipStreamDestroy(s->stream);
 }
 
@@ -883,6 +888,9 @@ int surf_enqueue(mif_surf* s, const void* d_pixels, int nf)
     hipStream_t st = s->stream;
     const int w = s->W, h = s->H;
     MIF_HIP(hipEventRecord(s->ev0, st));
+    const bool tm = s->timing;
+    s->timed = false;
+    if (tm) MIF_HIP(hipEventRecord(s->ev_stage[0], st));
     // layers that are empty keep zero-sized slots; the pools are cleared so that
     // positions no work item writes read as zero, as in freshly allocated buffers
     // (one memset: response and laplacian pools, acceptance mask, row counts)
@@ -893,9 +901,11 @@ int surf_enqueue(mif_surf* s, const void* d_pixels, int nf)
         hipLaunchKernelGGL(k_scan_cols, dim3((w + 63) / 64, nf), dim3(64 * kColWaves), 0, st, s->integral, w, h);
     else
         hipLaunchKernelGGL(k_scan_cols_serial, dim3((w + 63) / 64, nf), dim3(64), 0, st, s->integral, w, h);
+    if (tm) MIF_HIP(hipEventRecord(s->ev_stage[1], st));
     const int lw = std::max(s->tab.l[0].w, 1), lh = std::max(s->tab.l[0].h, 1);
     hipLaunchKernelGGL(k_hessian, dim3((lw + 15) / 16, (lh + 15) / 16, kLayers * nf), dim3(256), 0, st,
                        (const float*)s->integral, w, h, s->tab, s->responses, s->laplacians, s->pool);
+    if (tm) MIF_HIP(hipEventRecord(s->ev_stage[2], st));
     hipLaunchKernelGGL(k_nms_mark, dim3(s->nms.words, s->nms_max_h, kNms * nf), dim3(64), 0, st, s->tab, s->nms,
                        (const float*)s->responses, (const int*)s->laplacians, kThres, s->mask, s->rowcnt, s->pool);
     hipLaunchKernelGGL(k_scan_counts, dim3(nf), dim3(1024), 0, st, (const int*)s->rowcnt, s->rowoff, s->nms.rows,
@@ -909,8 +919,10 @@ int surf_enqueue(mif_surf* s, const void* d_pixels, int nf)
     // frame walk its list with the grid's stride. One frame gets a block per two list slots, batches get
     // fewer blocks per frame so that the launch stays at a few thousand blocks.
     const int per_frame = std::max(64, std::min(kMaxIpts / 2, 16384 / nf));
+    if (tm) MIF_HIP(hipEventRecord(s->ev_stage[3], st));
     hipLaunchKernelGGL(k_orientation, dim3(per_frame, nf), dim3(128), 0, st, (const float*)s->integral, w, h,
                        (const float2*)s->pos, (const float*)s->scale, (const int*)s->counts, s->orient);
+    if (tm) MIF_HIP(hipEventRecord(s->ev_stage[4], st));
     hipLaunchKernelGGL(k_descriptor, dim3(per_frame, nf), dim3(256), 0, st, (const float*)s->integral, w, h,
                        (const float2*)s->pos, (const float*)s->scale, (const float*)s->orient, (const int*)s->counts,
                        s->desc);
@@ -918,6 +930,10 @@ int surf_enqueue(mif_surf* s, const void* d_pixels, int nf)
                        (const float*)s->orient, (const int*)s->lap, (const float*)s->desc, (const int*)s->counts,
                        reinterpret_cast<uint32_t*>(s->packed));
     MIF_HIP(hipGetLastError());
+    if (tm) {
+        MIF_HIP(hipEventRecord(s->ev_stage[5], st));
+        s->timed = true;
+    }
     MIF_HIP(hipEventRecord(s->ev1, st));
     return MIF_OK;
 }
@@ -1053,6 +1069,29 @@ int mif_surf_run(mif_surf* s, const uint8_t* pixels, mif_ipoint* points, int cap
     if (n == 0) return MIF_OK;
     MIF_HIP(hipMemcpy(points, s->packed, (size_t)n * sizeof(mif_ipoint), hipMemcpyDeviceToHost));
     *count = n;
+    return MIF_OK;
+}
+
+int mif_surf_set_timing(mif_surf* s, int enable)
+{
+    if (!s) return MIF_ERR_INVALID_ARGUMENT;
+    mif::DeviceGuard guard(s->device);
+    if (enable && !s->ev_stage[0])
+        for (hipEvent_t& e : s->ev_stage) MIF_HIP(hipEventCreate(&e));
+    s->timing = enable != 0;
+    return MIF_OK;
+}
+
+int mif_surf_stage_times(mif_surf* s, float ms[MIF_SURF_STAGES])
+{
+    if (!s || !ms) return MIF_ERR_INVALID_ARGUMENT;
+    if (!s->timed) {
+        mif::set_error("mif_surf_stage_times: no batch has been enqueued with timing enabled");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
+    mif::DeviceGuard guard(s->device);
+    MIF_HIP(hipStreamSynchronize(s->stream));
+    for (int i = 0; i < MIF_SURF_STAGES; i++) MIF_HIP(hipEventElapsedTime(&ms[i], s->ev_stage[i], s->ev_stage[i + 1]));
     return MIF_OK;
 }
 

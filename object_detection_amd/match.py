@@ -122,6 +122,12 @@ class ShardedMatcher:
     def __del__(self):
         self.close()
 
+    def ranks(self):
+        """The handle's own view: {"nlocal", "nranks", "uses_rccl"} (mif_match_sharded_ranks)."""
+        nl, nr, v = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self._lib.mif_match_sharded_ranks(self._h, C.byref(nl), C.byref(nr), C.byref(v)))
+        return {"nlocal": nl.value, "nranks": nr.value, "uses_rccl": bool(v.value)}
+
     def uses_rccl(self):
         v = C.c_int()
         _lib.check(self._lib.mif_match_sharded_ranks(self._h, None, None, C.byref(v)))

@@ -77,6 +77,14 @@ class SiftExtractor:
         _lib.check(self._lib.mif_sift_snapshot_frame(self._h, frame, C.c_void_p(d_descriptors_ptr),
                                                      C.c_void_p(d_count_ptr)))
 
+    def pack_results(self, nframes, d_keypoints, d_orientations, d_descriptors, d_offsets, max_rows):
+        """The rows of the first nframes frames of the last batch back to back in the caller's device
+        arrays (integer addresses; orientations and descriptors may both be None), in stream order;
+        d_offsets takes int32[nframes + 2] (see mif_sift_pack_results)."""
+        _lib.check(self._lib.mif_sift_pack_results(
+            self._h, nframes, C.c_void_p(d_keypoints), C.c_void_p(d_orientations) if d_orientations else None,
+            C.c_void_p(d_descriptors) if d_descriptors else None, C.c_void_p(d_offsets), max_rows))
+
     def enqueue(self, d_pixels_ptr, nframes=1, want_descriptors=True):
         """d_pixels_ptr: integer device address of nframes frames of uint8 pixels, back to back."""
         _lib.check(self._lib.mif_sift_enqueue(self._h, C.c_void_p(d_pixels_ptr), nframes,

@@ -69,6 +69,17 @@ class SurfExtractor:
         _lib.check(self._lib.mif_surf_device_results(self._h, *[C.byref(x) for x in v]))
         return tuple(x.value for x in v)      # pos, scale, laplacian, orientation, descriptors, counts
 
+    STAGES = ("integral_image", "hessian_det", "non_max_supression", "getOrientation", "createDescriptors")
+
+    def set_timing(self, enable=True):
+        _lib.check(self._lib.mif_surf_set_timing(self._h, 1 if enable else 0))
+
+    def stage_times(self):
+        """ms per stage (STAGES) of the last batch enqueued with timing on."""
+        buf = (C.c_float * 5)()
+        _lib.check(self._lib.mif_surf_stage_times(self._h, buf))
+        return np.array(buf[:], dtype=np.float32)
+
     def integral(self, frame=0):
         out = np.empty((self.height, self.width), np.float32)
         _lib.check(self._lib.mif_surf_copy_integral_frame(self._h, frame, out.ctypes.data))

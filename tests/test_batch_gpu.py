@@ -257,3 +257,60 @@ def test_extraction_on_a_stream_with_a_share_of_the_compute_units():
     assert lib.mif_stream_create_masked(0, None, 8, C.byref(st)) != 0
     sparse = (C.c_uint32 * 8)(0x55555555, 0, 0, 0, 0, 0, 0, 0)
     assert lib.mif_stream_create_masked(0, sparse, 8, C.byref(st)) != 0 and b"contiguous" in lib.mif_last_error()
+    # refused before the runtime is called: a run that leaves some XCD without a compute unit, an empty
+    # mask, and bits beyond the device's compute units
+    few = (C.c_uint32 * 8)(0xF, 0, 0, 0, 0, 0, 0, 0)
+    assert lib.mif_stream_create_masked(0, few, 8, C.byref(st)) != 0 and b"XCDs" in lib.mif_last_error()
+    none = (C.c_uint32 * 8)()
+    assert lib.mif_stream_create_masked(0, none, 8, C.byref(st)) != 0
+    beyond = (C.c_uint32 * 16)(*([0] * 7 + [0xFF000000, 0xFF] + [0] * 7))
+    assert lib.mif_stream_create_masked(0, beyond, 16, C.byref(st)) != 0 and b"compute units" in lib.mif_last_error()
+
+
+def test_pack_results_equals_per_frame_copies():
+    """mif_sift_pack_results: the batch's rows back to back (frame-major, octave-major inside a frame, as
+    sift.cpp:1889-1911 appends them) equal the per-frame copies, which the tests above compare with the
+    checker; a frame without keypoints in some octave contributes nothing; max_rows cuts from the end."""
+    import torch
+    frames = _frames()
+    B = len(frames)
+    dev = torch.device("cuda:0")
+    px = torch.from_numpy(np.stack(frames)).to(dev)
+    ex = oda.SiftExtractor(256, 192, 1, batch=B)
+    ex.enqueue(px.data_ptr(), B)
+    per_frame = [ex.copy_results(f)[1] for f in range(B)]
+    totals = [len(f.keypoints) for f in per_frame]
+    assert sum(totals) > 100 and 0 in totals            # the flat frame has no keypoints
+    for nframes, max_rows in ((B, B * ex.capacity), (3, B * ex.capacity), (B, sum(totals) - 5), (B, 0)):
+        kp = torch.full((max(max_rows, 1), 4), -3.0, device=dev)
+        ori = torch.full((max(max_rows, 1),), -3.0, device=dev)
+        des = torch.full((max(max_rows, 1), 128), -3.0, device=dev)
+        off = torch.full((nframes + 2,), -9, dtype=torch.int32, device=dev)
+        ex.pack_results(nframes, kp.data_ptr(), ori.data_ptr(), des.data_ptr(), off.data_ptr(), max_rows)
+        ex.sync()
+        off = off.cpu().numpy()
+        want_off = np.concatenate([[0], np.cumsum(totals[:nframes])])
+        assert off[nframes + 1] == want_off[-1]
+        assert np.array_equal(off[:nframes + 1], np.minimum(want_off, max_rows))
+        n = int(off[nframes])
+        want_kp = np.concatenate([f.keypoints for f in per_frame[:nframes]])[:n]
+        want_ori = np.concatenate([f.orientations for f in per_frame[:nframes]])[:n]
+        want_des = np.concatenate([f.descriptors for f in per_frame[:nframes]])[:n]
+        assert np.array_equal(kp[:n].cpu().numpy().view(np.uint32), want_kp.view(np.uint32))
+        assert np.array_equal(ori[:n].cpu().numpy().view(np.uint32), want_ori.view(np.uint32))
+        assert np.array_equal(des[:n].cpu().numpy().view(np.uint32), want_des.view(np.uint32))
+        # nothing is written behind the packed rows
+        assert bool((kp[n:] == -3.0).all()) and bool((des[n:] == -3.0).all())
+    # detector only: no orientation / descriptor arrays
+    ex.enqueue(px.data_ptr(), B, want_descriptors=False)
+    kp = torch.zeros((B * ex.capacity, 4), device=dev)
+    off = torch.zeros((B + 2,), dtype=torch.int32, device=dev)
+    ex.pack_results(B, kp.data_ptr(), None, None, off.data_ptr(), B * ex.capacity)
+    ex.sync()
+    n = int(off[B].item())
+    want = np.concatenate([ex.copy_results(f, want_descriptors=False)[1].keypoints for f in range(B)])
+    assert n == len(want) and np.array_equal(kp[:n].cpu().numpy().view(np.uint32), want.view(np.uint32))
+    with pytest.raises(_lib.MifError):
+        ex.pack_results(B + 1, kp.data_ptr(), None, None, off.data_ptr(), 10)
+    with pytest.raises(_lib.MifError):
+        ex.pack_results(B, kp.data_ptr(), None, des.data_ptr(), off.data_ptr(), 10)

@@ -123,6 +123,11 @@ def test_bench_gpus_flag_starts_that_many_ranks():
         rec = json.loads(lines[0])
         assert rec["n_gpus"] == n and rec["config"]["world_size"] == n
         assert rec["config"]["rank_devices"] == list(range(n))
+        # the multi-rank fields of the full line: one time per rank, the sharded matcher's view of the
+        # ranks, and a frame-rendering pool that all ranks of the node can afford together
+        assert len(rec["per_rank_ms_per_step"]) == n and all(t >= 0 for t in rec["per_rank_ms_per_step"])
+        assert rec["matcher"]["sharded"]["nranks"] == n and "uses_rccl" in rec["matcher"]["sharded"]
+        assert 1 <= rec["frame_workers"] <= max(1, min(8, (os.cpu_count() or 1) // n))
 
 
 def test_bench_launcher_reports_a_failing_rank():
@@ -133,6 +138,55 @@ def test_bench_launcher_reports_a_failing_rank():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     # without a GPU every rank of a real run stops with "bench.py needs a GPU"; tiny frames keep it quick
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2",
-                          "--width", "64", "--height", "48"], env=env, capture_output=True, text=True, timeout=180)
+                          "--width", "64", "--height", "48", "--no-configs"], env=env, capture_output=True, text=True, timeout=180)
     assert out.returncode != 0
     assert "needs a GPU" in out.stderr
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_matcher_block_failures_are_failures():
+    """A multi-rank matcher block that raises is reported as failed (not as a pass with an `error` field),
+    a single-rank one re-raises, and a block that stalls makes the watchdog print the line with the error
+    and leave with a non-zero code on every rank, rank 0 included."""
+    import json
+    import threading
+    bench = _load_bench()
+
+    def boom():
+        raise RuntimeError("ncclAllGather: unhandled system error")
+
+    blk, ok, failed = bench.guarded_matcher_block(boom, rank=0, world=2, timeout_s=60, out={})
+    assert "unhandled system error" in blk["error"] and ok is False and failed is True
+    with pytest.raises(RuntimeError):
+        bench.guarded_matcher_block(boom, rank=0, world=1, timeout_s=60, out={})
+    blk, ok, failed = bench.guarded_matcher_block(lambda: ({"value": 1.0}, True), rank=1, world=2, timeout_s=60, out=None)
+    assert blk == {"value": 1.0} and ok is True and failed is False
+
+    for rank in (0, 1):
+        printed, left, release = [], [], threading.Event()
+
+        def emit(text, flush=False):
+            printed.append(text)
+
+        def leave(code):
+            left.append(code)
+            release.set()
+
+        def stalls():
+            release.wait(30)                   # a collective the other ranks never join
+            return {"value": 0.0}, True
+
+        out = {"metric": "x", "matcher": None}
+        bench.guarded_matcher_block(stalls, rank=rank, world=2, timeout_s=0.2, out=out, emit=emit, leave=leave)
+        assert left == [4]                     # non-zero on every rank
+        if rank == 0:
+            assert len(printed) == 1 and "did not finish" in json.loads(printed[0])["matcher"]["error"]
+        else:
+            assert printed == []

@@ -340,3 +340,59 @@ def test_million_row_database_through_64_screening_splits():
         # two bf16 passes over the database (too few queries for a sampled first pass), or none
         assert m.last_screen_passes() == (2.0 if screening else 0.0)
     assert (idx_o[:, 0] == perm).mean() > 0.98
+
+
+def test_production_dispatch_at_natural_size():
+    """16384 queries x 262144 rows x 128 through the default switches: at this size the matcher by itself
+    converts the database into its bf16 image (k_match_pack_rows), screens with k_match_screen4 and lets
+    the first pass sample the rows -- the path behind the 1 M x 1 M figure -- which last_screen_passes() < 2
+    shows. Compared with the CPU checker, bit for bit, including a row repeated 40 times inside one split
+    (that split's candidate list overflows), equal rows in different splits (the lower index wins) and
+    queries / rows placed on bf16 rounding boundaries (_adversarial_pair). The same search through the
+    library's sharding (two shards of 131072 rows on this GPU, each large enough for the same path)."""
+    import torch
+    from object_detection_amd.distributed import shard_range
+    dev = torch.device("cuda:0")
+    nd, nq = 262144, 16384
+    base = sift_like_descriptors(65536, seed=7)
+    db = np.concatenate([np.roll(base, r, axis=1) for r in range(nd // 65536)])
+    rng = np.random.RandomState(23)
+    perm = rng.permutation(nd)[:nq]
+    q = np.clip(db[perm] + rng.normal(0, 8, (nq, 128)), 0, 255).astype(np.float32)
+    aq, ad, awant = _adversarial_pair(600, 2000, 0, seed=901)
+    q[1000:1600] = aq
+    db[140000:142000] = ad
+    db[100000:100040] = q[3]                    # 40 copies inside one split
+    db[123] = db[200000] = q[5]                 # equal rows in different splits (and different shards)
+    db[nd - 1] = q[7]                           # the very last row
+    idx_o, dist_o = orc.match_top2(q, db)
+    assert list(idx_o[3]) == [100000, 100001] and list(idx_o[5]) == [123, 200000] and idx_o[7, 0] == nd - 1
+    assert np.array_equal(idx_o[1000:1600, 0], 140000 + awant)      # the construction survives the embedding
+    tq = torch.from_numpy(q).to(dev)
+    td = torch.from_numpy(db).to(dev)
+    m = oda.Matcher(nq, nd)
+    idx = torch.full((nq, 2), -9, dtype=torch.int32, device=dev)
+    dist = torch.zeros((nq, 2), dtype=torch.float32, device=dev)
+    m.top2_device(tq.data_ptr(), nq, td.data_ptr(), nd, 128, 128, idx.data_ptr(), dist.data_ptr())
+    torch.cuda.synchronize()
+    assert 1.0 < m.last_screen_passes() < 2.0           # sampled first pass: the large-search path ran
+    assert np.array_equal(idx.cpu().numpy(), idx_o)
+    assert np.array_equal(dist.cpu().numpy().view(np.uint32), dist_o.view(np.uint32))
+    m.close()
+
+    sm = oda.ShardedMatcher.local([0, 0], max_query=nq, max_shard_rows=nd // 2)
+    outs, ios = [], []
+    for r in range(2):
+        lo, hi = shard_range(nd, r, 2)
+        i2 = torch.full((nq, 2), -7, dtype=torch.int32, device=dev)
+        d2 = torch.full((nq, 2), -7.0, dtype=torch.float32, device=dev)
+        outs.append((i2, d2))
+        ios.append(dict(q=tq.data_ptr(), shard=td[lo:hi].data_ptr(), rows=hi - lo, offset=lo,
+                        idx2=i2.data_ptr(), dist2=d2.data_ptr()))
+    sm.search_all(ios, nq, 128, 128)
+    sm.sync()
+    assert 1.0 < sm.last_screen_passes() < 2.0
+    for i2, d2 in outs:
+        assert np.array_equal(i2.cpu().numpy(), idx_o)
+        assert np.array_equal(d2.cpu().numpy().view(np.uint32), dist_o.view(np.uint32))
+    sm.close()

@@ -98,10 +98,15 @@ def test_surf_batches_equal_single_frames(channels):
     ex = oda.SurfExtractor(w, h, channels, batch=4)
     dev = torch.device("cuda:0")
     S = orc.SurfOracle(w, h)
+    with pytest.raises(Exception):
+        ex.stage_times()                                    # nothing has been timed yet
+    ex.set_timing(True)
     for lo, hi in ((0, 4), (4, 5), (1, 3)):
         px = torch.from_numpy(np.stack(frames[lo:hi])).to(dev)
         torch.cuda.synchronize()
         ex.enqueue_batch(px.data_ptr(), hi - lo)
+        t = ex.stage_times()                                # per stage, HIP events on the handle's stream
+        assert t.shape == (len(ex.STAGES),) and np.all(t >= 0) and 0 < t.sum() < 1000
         for f in range(hi - lo):
             n = S.run(frames[lo + f])
             pts, raw = ex.copy_points(f)
