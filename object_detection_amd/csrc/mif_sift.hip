@@ -324,7 +324,77 @@ __device__ __forceinline__ void stage_window(const char* __restrict__ src, int w
     }
 }
 
-template <int FR, int SRC>
+// The same window, staged four pixels per lane and load: for images whose width is a multiple of four
+// (and whose frames start on a 4-byte boundary, 16-byte for float sources) a lane fetches the aligned
+// group of four pixels it owns with ONE load -- 16 bytes of a float image, 12 bytes of a BGR frame,
+// 4 bytes of a gray frame -- instead of one (for BGR: unaligned) load per pixel, which cuts the
+// window's load instructions to a fifth. The window is extended on the left by LS columns so that it
+// starts at a multiple of four; a group then lies inside the image as a whole or not at all. A wave's
+// load covers 8 groups x 8 rows (128 / 96 / 32 contiguous bytes of 8 rows); with the transposed layout
+// s_in[column * PT + row] (PT odd) the four stores of such a block put two lanes on every LDS bank, the
+// minimum for 64 lanes. All loads of a thread are issued before its first LDS store.
+template <int SRC, int EW, int EH, int PT, int LS>
+__device__ __forceinline__ void stage_window4(const char* __restrict__ src, int w, int h, int wx0, int wy0, int tid,
+                                              float* __restrict__ s_in)
+{
+    static_assert(SRC == kSrcFloat || SRC == kSrcGrayU8 || SRC == kSrcBgrU8, "sources with four pixels per load");
+    constexpr int G = (EW + LS + 3) / 4;                 // groups per window row
+    constexpr int GB = (G + 7) / 8, RB = (EH + 7) / 8;   // blocks of 8 groups x 8 rows
+    constexpr int NBLK = GB * RB;
+    constexpr int ITER = (NBLK + 3) / 4;                 // blocks per wave
+    constexpr int NW = SRC == kSrcFloat ? 4 : SRC == kSrcBgrU8 ? 3 : 1;     // 32-bit words per group
+    constexpr unsigned px_bytes = SRC == kSrcFloat ? 4u : SRC == kSrcBgrU8 ? 3u : 1u;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lg = lane & 7, lr = lane >> 3;
+    const unsigned row_bytes = px_bytes * (unsigned)w;
+    uint32_t raw[ITER][NW];
+#pragma unroll
+    for (int it = 0; it < ITER; it++) {
+        const int blk = min(wv + 4 * it, NBLK - 1);      // wave-uniform; a surplus turn repeats the last block
+        const int rb = blk / GB, gb = blk - rb * GB;
+        const int gx = wx0 - LS + 4 * (gb * 8 + lg), gy = wy0 + rb * 8 + lr;
+        const unsigned off = (unsigned)min(max(gy, 0), h - 1) * row_bytes + (unsigned)min(max(gx, 0), w - 4) * px_bytes;
+        const uint32_t* at = (const uint32_t*)(src + off);
+#pragma unroll
+        for (int k = 0; k < NW; k++) raw[it][k] = at[k];
+    }
+#pragma unroll
+    for (int it = 0; it < ITER; it++) {
+        const int blk = wv + 4 * it;
+        if (blk >= NBLK) break;                          // wave-uniform
+        const int rb = blk / GB, gb = blk - rb * GB;
+        const int g = gb * 8 + lg, r = rb * 8 + lr;
+        const int gx = wx0 - LS + 4 * g, gy = wy0 + r;
+        const bool inside = gx >= 0 && gx < w && gy >= 0 && gy < h;
+        float v[4];
+        if (SRC == kSrcFloat) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = __builtin_bit_cast(float, raw[it][j]);
+        } else if (SRC == kSrcGrayU8) {
+            const uint32_t w0 = raw[it][0];
+            v[0] = (float)(w0 & 255u) / 255.0f;
+            v[1] = (float)((w0 >> 8) & 255u) / 255.0f;
+            v[2] = (float)((w0 >> 16) & 255u) / 255.0f;
+            v[3] = (float)(w0 >> 24) / 255.0f;
+        } else {
+            const uint32_t w0 = raw[it][0], w1 = raw[it][NW > 1 ? 1 : 0], w2 = raw[it][NW > 2 ? 2 : 0];
+            v[0] = gray_of_bgr((float)(w0 & 255u), (float)((w0 >> 8) & 255u), (float)((w0 >> 16) & 255u));
+            v[1] = gray_of_bgr((float)(w0 >> 24), (float)(w1 & 255u), (float)((w1 >> 8) & 255u));
+            v[2] = gray_of_bgr((float)((w1 >> 16) & 255u), (float)(w1 >> 24), (float)(w2 & 255u));
+            v[3] = gray_of_bgr((float)((w2 >> 8) & 255u), (float)((w2 >> 16) & 255u), (float)(w2 >> 24));
+        }
+        if (r < EH) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int c = 4 * g + j - LS;
+                if (c >= 0 && c < EW) s_in[c * PT + r] = inside ? v[j] : 0.0f;
+            }
+        }
+    }
+}
+
+template <int FR, int SRC, bool A4>
 __global__ __launch_bounds__(256) void k_blur_level(const void* __restrict__ src_any, size_t src_stride,
                                                     float* __restrict__ dst, size_t pyr_stride, int w, int h,
                                                     Taps taps,
@@ -363,7 +433,12 @@ __global__ __launch_bounds__(256) void k_blur_level(const void* __restrict__ src
     const char* const src = (const char*)src_any + (size_t)z * src_stride * ((SRC == kSrcFloat || SRC == kSrcDecimated) ? 4 : 1);
     dst += (size_t)z * pyr_stride;
 
-    stage_window<SRC, EW, EH, PT>(src, w, h, x0 - FR, y0 - FR, lane, wv, zero_row, s_in);
+    if (A4 && SRC != kSrcDecimated) {
+        constexpr int LS = (4 - FR % 4) % 4;     // x0 - FR - LS is a multiple of four
+        stage_window4<SRC == kSrcDecimated ? kSrcFloat : SRC, EW, EH, PT, LS>(src, w, h, x0 - FR, y0 - FR, tid, s_in);
+    } else {
+        stage_window<SRC, EW, EH, PT>(src, w, h, x0 - FR, y0 - FR, lane, wv, zero_row, s_in);
+    }
     __syncthreads();
 
     // vertical-pass mapping: columns 2 xp, 2 xp + 1, rows R yc .. R yc + R - 1
@@ -458,7 +533,7 @@ __global__ __launch_bounds__(256) void k_blur_level(const void* __restrict__ src
 // thread moves a phase's operands into registers before the phase's results overwrite them.
 // The extended tile starts one column further left when FB is odd (`LEAD`), so that the column pairs
 // of the vertical pass start at even x and level a is stored with 8-byte stores like level b.
-template <int FA, int FB, int SRC>
+template <int FA, int FB, int SRC, bool A4>
 __global__ __launch_bounds__(256) void k_blur_pair(const void* __restrict__ src_any, size_t src_stride,
                                                    float* __restrict__ dst_a, float* __restrict__ dst_b,
                                                    size_t pyr_stride, int w, int h, Taps taps_a, Taps taps_b,
@@ -505,7 +580,12 @@ __global__ __launch_bounds__(256) void k_blur_pair(const void* __restrict__ src_
     dst_b += (size_t)z * pyr_stride;
     const int ax0 = x0 - FB - LEAD, ay0 = y0 - FB;       // image position of the extended tile's corner
 
-    stage_window<SRC, EW0, EH0, PT0>(src, w, h, ax0 - FA, ay0 - FA, lane, wv, zero_row, s_buf);
+    if (A4 && SRC != kSrcDecimated) {
+        constexpr int LS = (4 - (FA + FB + LEAD) % 4) % 4;
+        stage_window4<SRC == kSrcDecimated ? kSrcFloat : SRC, EW0, EH0, PT0, LS>(src, w, h, ax0 - FA, ay0 - FA, tid, s_buf);
+    } else {
+        stage_window<SRC, EW0, EH0, PT0>(src, w, h, ax0 - FA, ay0 - FA, lane, wv, zero_row, s_buf);
+    }
     __syncthreads();
 
     // ---- H_a: s_buf[column * PT0 + row] -> s_buf[row * PHA + column]
@@ -1358,6 +1438,16 @@ __global__ __launch_bounds__(64) void k_orientation(const float4* __restrict__ k
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
 
+// The private 9-bin histograms of a block's 128 threads lie bin-major in LDS, s_des[bin][thread]: a
+// thread's bins are kDescStride floats apart, so whatever bins the lanes of a wave update, lane t is in
+// bank t % 32 and no two lanes of a half-wave meet in a bank. (Thread-major, 9 floats per thread, the
+// bank is (9 t + bin) % 32 and lanes with different bins collide: 3.95 conflict cycles per access.)
+#ifndef MIF_DESC_STRIDE
+#define MIF_DESC_STRIDE 128
+#endif
+constexpr int kDescStride = MIF_DESC_STRIDE;       // 128: bin-major; 1: thread-major (the form kept for comparison)
+constexpr int kDescThread = kDescStride == 1 ? 9 : 1;
+
 // One accepted window sample of kDescriptor (sift.cpp:669-699): weights, orientation bin and the
 // update of the lane's private histogram d[9]. (nx, ny) are the sample's coordinates in units of the
 // cell size relative to the cell centre, |nx|, |ny| < 1; g2 is the gradient plane's entry.
@@ -1397,8 +1487,8 @@ __device__ __forceinline__ void desc_accumulate(float* __restrict__ d, float nx,
     const int fo0 = (int)ffo;
     const float do0 = tth - ffo;
     const int fo = fo0 & 7;             // fo0 is in 0..8; same as the reference's % 8
-    d[fo] += (1.0f - do0) * wgt;
-    d[fo + 1] += do0 * wgt;
+    d[fo * kDescStride] += (1.0f - do0) * wgt;
+    d[(fo + 1) * kDescStride] += do0 * wgt;
 }
 
 // sift.cpp:585-709 kDescriptor fused with sift.cpp:712-765 kNormalize. One
@@ -1417,7 +1507,7 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
                                                     int o, int cap, const int* __restrict__ counts,
                                                     float* __restrict__ desc)
 {
-    __shared__ float s_des[16][8][9];
+    __shared__ float s_des[9 * 128];
     __shared__ float s_val[128];
     __shared__ float s_sq[128];
     __shared__ float s_norm;
@@ -1433,13 +1523,13 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
     const int lid = tid & 7;
     const int bid = tid >> 3;
     const int ix = bid & 3, iy = bid >> 2;
-    float* d = s_des[bid][lid];
+    float* d = s_des + tid * kDescThread;
     // the grid's x extent is far smaller than the list capacity (most of which stays empty):
     // a block walks the frame's keypoints with the grid's stride
     for (int k = blockIdx.x; k < n; k += gridDim.x) {      // uniform over the block
     const int gi = first + k;
 #pragma unroll
-    for (int i = 0; i < 9; i++) d[i] = 0.0f;
+    for (int i = 0; i < 9; i++) d[i * kDescStride] = 0.0f;
 
     const float4 f4 = kp[gi];
     const float p2o = mif_pow2i(o);
@@ -1602,11 +1692,11 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
             if (mif_fabsf(nx) < 1.0f && mif_fabsf(ny) < 1.0f) desc_accumulate(d, nx, ny, g2, offx, offy, ang);
         }
     }
-    d[0] += d[8];
+    d[0] += d[8 * kDescStride];
     __syncthreads();
     float bin = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 8; i++) bin += s_des[bid][i][lid];
+    for (int i = 0; i < 8; i++) bin += s_des[(bid * 8 + i) * kDescThread + lid * kDescStride];
 
     // normalise -> clamp 0.2 -> normalise -> x512 -> clamp 255
     s_val[tid] = bin;
@@ -1820,6 +1910,23 @@ struct mif_sift {
 
 namespace {
 
+// Whether the staging may fetch aligned groups of four pixels (stage_window4): the width a multiple of
+// four, and every frame's first pixel on a 16-byte (float image) resp. 4-byte (8-bit frame) boundary.
+// Used for BGR frames only: measured on 256 1080p frames it takes the BGR launch from 1.70 to 1.54 ms
+// (one aligned 12-byte load in place of four unaligned 4-byte ones), while the float launches get slower
+// (radius 6 / 7 / 9 / 11: 0.38 -> 0.40, 0.39 -> 0.42, 0.42 -> 0.49, 0.48 -> 0.56 ms) and so does the
+// launch that reads 8-bit gray frames (32 4K frames: 0.80 -> 0.84 ms): their plain staging loads are
+// coalesced already and cost a scalar row base each, the grouped form pays per-lane address and range
+// arithmetic.
+bool four_pixel_loads(const void* src, size_t src_stride, int w, int src_kind)
+{
+    static const bool off = getenv("MIF_NO_WIDE_STAGING") != nullptr;       // A/B switch
+    if (off || w % 4 != 0 || w < 4) return false;
+    const size_t unit = src_kind == kSrcFloat ? 4 : 1;                       // bytes per element of src_stride
+    const size_t align = src_kind == kSrcFloat ? 16 : 4;
+    return reinterpret_cast<uintptr_t>(src) % align == 0 && (src_stride * unit) % align == 0;
+}
+
 template <int FR, int SRC = kSrcFloat>
 void launch_blur_fr(const void* src, size_t src_stride, float* dst, size_t pyr_stride, int w, int h, int nframes,
                     const Taps& t, const float* zero_row, hipStream_t st)
@@ -1827,8 +1934,12 @@ void launch_blur_fr(const void* src, size_t src_stride, float* dst, size_t pyr_s
     const int tiles_x = (w + kBlurTile - 1) / kBlurTile, tiles_y = (h + kBlurTile - 1) / kBlurTile;
     const int ntiles = tiles_x * tiles_y * nframes;
     const int blocks = 8 * ((ntiles + 7) / 8);             // one equal share of the tiles per XCD
-    hipLaunchKernelGGL((k_blur_level<FR, SRC>), dim3(blocks), dim3(256), 0, st, src, src_stride, dst, pyr_stride, w, h,
-                       t, tiles_x, tiles_y, ntiles, zero_row);
+    if (SRC == kSrcBgrU8 && four_pixel_loads(src, src_stride, w, SRC))
+        hipLaunchKernelGGL((k_blur_level<FR, SRC, true>), dim3(blocks), dim3(256), 0, st, src, src_stride, dst,
+                           pyr_stride, w, h, t, tiles_x, tiles_y, ntiles, zero_row);
+    else
+        hipLaunchKernelGGL((k_blur_level<FR, SRC, false>), dim3(blocks), dim3(256), 0, st, src, src_stride, dst,
+                           pyr_stride, w, h, t, tiles_x, tiles_y, ntiles, zero_row);
 }
 
 // Tap radius of level 0 (sigma 1.6): the only radius whose kernel exists for every source kind.
@@ -1866,8 +1977,12 @@ void launch_blur_pair_fr(const void* src, size_t src_stride, float* dst_a, float
     const int tiles_x = (w + kBlurTile - 1) / kBlurTile, tiles_y = (h + kBlurTile - 1) / kBlurTile;
     const int ntiles = tiles_x * tiles_y * nframes;
     const int blocks = 8 * ((ntiles + 7) / 8);             // one equal share of the tiles per XCD
-    hipLaunchKernelGGL((k_blur_pair<FA, FB, SRC>), dim3(blocks), dim3(256), 0, st, src, src_stride, dst_a, dst_b,
-                       pyr_stride, w, h, ta, tb, tiles_x, tiles_y, ntiles, zero_row);
+    if (SRC == kSrcBgrU8 && four_pixel_loads(src, src_stride, w, SRC))
+        hipLaunchKernelGGL((k_blur_pair<FA, FB, SRC, true>), dim3(blocks), dim3(256), 0, st, src, src_stride, dst_a,
+                           dst_b, pyr_stride, w, h, ta, tb, tiles_x, tiles_y, ntiles, zero_row);
+    else
+        hipLaunchKernelGGL((k_blur_pair<FA, FB, SRC, false>), dim3(blocks), dim3(256), 0, st, src, src_stride, dst_a,
+                           dst_b, pyr_stride, w, h, ta, tb, tiles_x, tiles_y, ntiles, zero_row);
 }
 
 // Two consecutive levels in one launch (k_blur_pair). Returns false when no kernel exists for the

@@ -14,7 +14,9 @@
 //    the interest points are then written in the fixed order (launch, row,
 //    column) instead of atomic arrival order;
 //  * the 109 orientation samples of a point sit in ascending work-item order.
+#include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include <vector>
@@ -65,6 +67,11 @@ __constant__ float c_gauss25[49] = {
     0.00131955648461f, 0.00103799989504f, 0.00069579213743f, 0.00039744277546f, 0.00019345616757f, 0.00008024231247f, 0.00002836202103f};
 // work items of getOrientationStep1 (13 x 13 grid) with i*i + j*j < 36, ascending
 __constant__ unsigned char c_orient_item[109];
+// Which of the 109 samples thread t of the orientation kernel evaluates: the samples sorted by (row,
+// column) of the 13 x 13 grid, so that the lanes of a wave read along image rows (in work-item order the
+// row changes from lane to lane and every lane's load lands in a cache line of its own). The results
+// still go to the sample's own slot: the sums that follow run over the slots in work-item order.
+__constant__ unsigned char c_orient_slot[109];
 
 // ---------------------------------------------------------- integral image
 
@@ -140,6 +147,13 @@ __global__ __launch_bounds__(256) void k_scan_rows(const uint8_t* __restrict__ p
     }
 }
 
+// (Two forms of the row pass that keep the tree in registers, a lane per row like k_scan_cols has a lane
+// per column, were measured on 64 1080p BGR frames against the 315 us of the wave-per-row form above:
+// each lane reading and writing its own row as 16-byte words took 305 us -- every instruction then
+// touches 64 cache lines for 16 bytes each --, and a 64 x 64 tile transposed through LDS on the way in
+// and out took 1143 us: 64 rows per wave leave 1088 waves for 64 frames, one per SIMD, each a long
+// serial chain. The wave-per-row form has 69 120 waves to hide its cross-lane moves behind.)
+
 // Column pass: the same scan along y (the reference transposes, scans rows and transposes back,
 // ccl_surf.cpp:504-539): blocks of 64 rows are scanned with the Kogge-Stone tree and every block adds
 // the running total of the blocks above it, prev_k = (((0 + t_0) + t_1) + ...) + t_(k-1), t = last
@@ -150,19 +164,22 @@ __global__ __launch_bounds__(256) void k_scan_rows(const uint8_t* __restrict__ p
 // publishes its total; after a barrier it sums the totals of the blocks above it in order, adds and
 // stores. The trees of all row blocks of a strip thus run side by side; only the short chain of totals
 // is sequential. Strips taller than 16 blocks take several rounds.
-constexpr int kColWaves = 16;
+constexpr int kColWaves = 16;           // most waves of a workgroup
 constexpr int kColMaxBlocks = 128;      // row blocks per strip the totals table holds (8192 rows)
 
+// (Workgroups of 9 waves, so that the 17 row blocks of 1080 rows take two equally full rounds instead of
+// 16 + 1, were measured: 415 instead of 368 us per 64 frames.)
 __global__ __launch_bounds__(64 * kColWaves) void k_scan_cols(float* __restrict__ img, int w, int h)
 {
     __shared__ float s_tot[kColMaxBlocks * 64];      // [row blocks][64]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int nwaves = (int)(blockDim.x >> 6);
     const int x = blockIdx.x * 64 + lane;
     const bool live = x < w;
     img += (size_t)blockIdx.y * w * h;
     const int nblocks = (h + 63) / 64;
-    for (int kb0 = 0; kb0 < nblocks; kb0 += kColWaves) {     // uniform over the workgroup
+    for (int kb0 = 0; kb0 < nblocks; kb0 += nwaves) {        // uniform over the workgroup
         const int kb = kb0 + wave;
         const int y0 = kb * 64;
         float a[64];
@@ -270,10 +287,12 @@ __device__ __forceinline__ void haar_xy(const float* __restrict__ img, int w, in
 // guard only checks the image bounds and writes one element past the row).
 __global__ __launch_bounds__(256) void k_hessian(const float* __restrict__ img, int width, int height, LayerTable tab,
                                                  float* __restrict__ responses, int* __restrict__ laplacians,
-                                                 size_t pool)
+                                                 size_t pool, int first_layer)
 {
-    const int frame = blockIdx.z / kLayers;
-    const LayerDesc L = tab.l[blockIdx.z - frame * kLayers];
+    // grid.z = (layers first_layer .. kLayers - 1) x frames
+    const int nlayers = kLayers - first_layer;
+    const int frame = blockIdx.z / nlayers;
+    const LayerDesc L = tab.l[first_layer + blockIdx.z - frame * nlayers];
     img += (size_t)frame * width * height;
     responses += (size_t)frame * pool;
     laplacians += (size_t)frame * pool;
@@ -300,6 +319,103 @@ __global__ __launch_bounds__(256) void k_hessian(const float* __restrict__ img, 
     Dxy *= inverse_area;
     responses[L.off + idy * L.w + idx] = (Dxx * Dyy - 0.81f * Dxy * Dxy);
     laplacians[L.off + idy * L.w + idx] = (Dxx + Dyy >= 0 ? 1 : 0);
+}
+
+// The four layers of the first octave (filters 9, 15, 21, 27) share the sampling step and the output
+// grid, and together hold 87 % of all responses at 1080p. Read straight from memory every response costs
+// 32 scattered loads (a vector-cache access per lane and load: the launch is bound by those). Here a block
+// stages the part of the integral image that its 16 x 16 output positions touch for the largest of the
+// filters -- (16 - 1) step + 1 pixels extended by the filter's reach, 104 x 104 values at step 5 -- into
+// LDS once, with coalesced row loads and zeros where the row or column index is negative (what
+// BoxIntegral returns for those corners), and evaluates the four layers from there: the same corner
+// values, the same expressions, hence the same bits. Lanes run along x with a stride of `step` values,
+// which is odd, so the LDS reads of a row of outputs are conflict-free.
+constexpr int kHessTileOut = 16;
+constexpr int kHessFirstLayers = 4;              // layers served by the staged form
+constexpr int kHessMaxFilter = 27;
+constexpr int kHessReachLo = (kHessMaxFilter - 1) / 2 + 1 + 1;   // b + 1 values before the sample position
+constexpr int kHessReachHi = (kHessMaxFilter - 1) / 2;           // b - 1 values behind it
+constexpr int kHessWin = (kHessTileOut - 1) * kSampleStep + 1 + kHessReachLo + kHessReachHi;   // 104
+constexpr int kHessPitch = kHessWin + 1;
+
+// BoxIntegral (hessianDet_kernel.cl:77-103) on the staged window: (wy0, wx0) is the image position of
+// the window's first value; clamped indices below zero meet the zeros stored there.
+__device__ __forceinline__ float box_integral_staged(const float* __restrict__ s_win, int wy0, int wx0, int width,
+                                                     int height, int row, int col, int rows, int cols)
+{
+    const int r1 = min(row, height) - 1 - wy0;
+    const int c1 = min(col, width) - 1 - wx0;
+    const int r2 = min(row + rows, height) - 1 - wy0;
+    const int c2 = min(col + cols, width) - 1 - wx0;
+    const float A = s_win[r1 * kHessPitch + c1];
+    const float B = s_win[r1 * kHessPitch + c2];
+    const float C = s_win[r2 * kHessPitch + c1];
+    const float D = s_win[r2 * kHessPitch + c2];
+    return fmaxf(0.0f, A - B - C + D);
+}
+
+// grid (ceil(layer w / 16), ceil(layer h / 16), frames); the layers 0 .. kHessFirstLayers - 1 must share
+// w, h and step = kSampleStep and have filters of at most kHessMaxFilter (checked by the host).
+__global__ __launch_bounds__(256) void k_hessian_staged(const float* __restrict__ img, int width, int height,
+                                                        LayerTable tab, float* __restrict__ responses,
+                                                        int* __restrict__ laplacians, size_t pool)
+{
+    __shared__ float s_win[kHessWin * kHessPitch];
+    const int frame = blockIdx.z;
+    img += (size_t)frame * width * height;
+    responses += (size_t)frame * pool;
+    laplacians += (size_t)frame * pool;
+    const int tid = threadIdx.x;
+    const int wx0 = (int)blockIdx.x * kHessTileOut * kSampleStep - kHessReachLo;
+    const int wy0 = (int)blockIdx.y * kHessTileOut * kSampleStep - kHessReachLo;
+    {
+        // all of a thread's loads are issued before its first LDS store (clamped addresses, zeros selected
+        // afterwards), so that their latencies overlap
+        constexpr int kTurns = (kHessWin * kHessWin + 255) / 256;
+        float v[kTurns];
+#pragma unroll
+        for (int it = 0; it < kTurns; it++) {
+            const int i = min(tid + 256 * it, kHessWin * kHessWin - 1);
+            const int ly = i / kHessWin, lx = i - ly * kHessWin;
+            const int gy = min(max(wy0 + ly, 0), height - 1), gx = min(max(wx0 + lx, 0), width - 1);
+            v[it] = img[gy * width + gx];
+        }
+#pragma unroll
+        for (int it = 0; it < kTurns; it++) {
+            const int i = tid + 256 * it;
+            const int ly = i / kHessWin, lx = i - ly * kHessWin;
+            const int gy = wy0 + ly, gx = wx0 + lx;
+            const bool inside = gy >= 0 && gx >= 0 && gy < height && gx < width;
+            if (i < kHessWin * kHessWin) s_win[ly * kHessPitch + lx] = inside ? v[it] : 0.0f;
+        }
+    }
+    __syncthreads();
+    const int idx = blockIdx.x * kHessTileOut + (tid & 15);
+    const int idy = blockIdx.y * kHessTileOut + (tid >> 4);
+    const int lw = tab.l[0].w, lh = tab.l[0].h;
+    if (idx >= lw || idy >= lh) return;
+    const int r = idy * kSampleStep;
+    const int c = idx * kSampleStep;
+    if (r >= height || c >= width) return;
+#pragma unroll
+    for (int li = 0; li < kHessFirstLayers; li++) {
+        const LayerDesc L = tab.l[li];
+        const int w = L.filter;
+        const int l = L.filter / 3;
+        const int b = (L.filter - 1) / 2 + 1;
+        const float inverse_area = 1.0f / (w * w);
+#define MIF_BOX(row, col, rows, cols) box_integral_staged(s_win, wy0, wx0, width, height, row, col, rows, cols)
+        float Dxx = MIF_BOX(r - l + 1, c - b, 2 * l - 1, w) - MIF_BOX(r - l + 1, c - l / 2, 2 * l - 1, l) * 3;
+        float Dyy = MIF_BOX(r - b, c - l + 1, w, 2 * l - 1) - MIF_BOX(r - l / 2, c - l + 1, l, 2 * l - 1) * 3;
+        float Dxy = MIF_BOX(r - l, c + 1, l, l) + MIF_BOX(r + 1, c - l, l, l) - MIF_BOX(r - l, c - l, l, l) -
+                    MIF_BOX(r + 1, c + 1, l, l);
+#undef MIF_BOX
+        Dxx *= inverse_area;
+        Dyy *= inverse_area;
+        Dxy *= inverse_area;
+        responses[L.off + idy * L.w + idx] = (Dxx * Dyy - 0.81f * Dxy * Dxy);
+        laplacians[L.off + idy * L.w + idx] = (Dxx + Dyy >= 0 ? 1 : 0);
+    }
 }
 
 // ------------------------------------------------------------------- NMS
@@ -520,6 +636,41 @@ __global__ __launch_bounds__(256) void k_nms_emit(LayerTable tab, NmsTable nms, 
 
 // ------------------------------------------------------------ orientation
 
+// How the orientation and descriptor kernels deal a frame's points to the blocks of their
+// (blocks per frame, frames) grid. Both gather from the integral image around their points, and the
+// gathers miss the L2 a lot when every XCD sees points from all over the frame (64 1080p frames: the
+// descriptor kernel fetched 163 MB per frame, twenty times the image). The list is ordered
+// (non_max_supression launch, row, column): a launch is one scale, and within a launch the points come in
+// raster order. So every XCD takes the same eighth -- a band of image rows -- of EVERY launch
+// (consecutive blocks of a grid go to consecutive XCDs; the grid's x extent is a multiple of 8), and an
+// XCD's blocks walk that band together, consecutive points to consecutive blocks. Every XCD thus gets
+// every scale (one contiguous eighth of the whole list per XCD left the XCD with the coarse points,
+// whose windows are far larger, working long after the others: 6.19 instead of 3.39 ms), and its L2
+// holds one band of the image.
+struct PointWalk {
+    int start[kNms + 1];             // first point of every launch in the frame's list; [kNms] = the count
+    int xcd, first, stride;          // this block: XCD, position among the XCD's blocks, their number
+};
+
+__device__ __forceinline__ PointWalk point_walk(const NmsTable& nms, const int* __restrict__ rowoff, int n)
+{
+    PointWalk W;
+#pragma unroll
+    for (int i = 0; i < kNms; i++) W.start[i] = (nms.n[i].row0 < nms.rows) ? min(rowoff[nms.n[i].row0], n) : n;
+    W.start[kNms] = n;
+    W.xcd = (int)(blockIdx.x & 7u);
+    W.first = (int)(blockIdx.x >> 3);
+    W.stride = (int)(gridDim.x >> 3);
+    return W;
+}
+// points of launch i this block handles: lo + first, lo + first + stride, ... below hi
+__device__ __forceinline__ void walk_range(const PointWalk& W, int i, int* lo, int* hi)
+{
+    const int len = W.start[i + 1] - W.start[i];
+    *lo = W.start[i] + (int)((long long)W.xcd * len / 8) + W.first;
+    *hi = W.start[i] + (int)((long long)(W.xcd + 1) * len / 8);
+}
+
 // atan of a non-negative (possibly infinite or NaN) argument
 __device__ __forceinline__ float atan_pos(float v)
 {
@@ -550,7 +701,8 @@ __device__ __forceinline__ float gaussian(float x, float y, float sig)
 // sample order, then the reference's max-magnitude tree picks the winner.
 __global__ __launch_bounds__(128) void k_orientation(const float* __restrict__ img, int w, int h,
                                                      const float2* __restrict__ pos, const float* __restrict__ scale,
-                                                     const int* __restrict__ counts, float* __restrict__ orientation)
+                                                     const int* __restrict__ counts, float* __restrict__ orientation,
+                                                     NmsTable nms, const int* __restrict__ rowoff)
 {
     __shared__ float s_rx[109], s_ry[109], s_rz[109];
     __shared__ float s_sx[42], s_sy[42];
@@ -561,17 +713,22 @@ __global__ __launch_bounds__(128) void k_orientation(const float* __restrict__ i
         scale += f * kMaxIpts;
         orientation += f * kMaxIpts;
         counts += f * 2;
+        rowoff += f * nms.rows;
     }
     const int tid = threadIdx.x;
     const int n_ipts = counts[0];
-    // the grid's x extent is smaller than the list capacity: a block walks the frame's points with the
-    // grid's stride (uniform over the block)
-    for (int ip = blockIdx.x; ip < n_ipts; ip += gridDim.x) {
+    // which points the block handles: see PointWalk (uniform over the block)
+    const PointWalk walk = point_walk(nms, rowoff, n_ipts);
+    for (int li = 0; li < kNms; li++) {
+    int ip_lo, ip_hi;
+    walk_range(walk, li, &ip_lo, &ip_hi);
+    for (int ip = ip_lo; ip < ip_hi; ip += walk.stride) {
     const int s = (int)mif_roundf(scale[ip]);
     const int r = (int)mif_roundf(pos[ip].y);
     const int c = (int)mif_roundf(pos[ip].x);
     if (tid < 109) {
-        const int localId = c_orient_item[tid];
+        const int slot = c_orient_slot[tid];
+        const int localId = c_orient_item[slot];
         const int i = localId / 13 - 6;
         const int j = localId % 13 - 6;
         const float gauss = c_gauss25[7 * c_tab_id[i + 6] + c_tab_id[j + 6]];
@@ -579,9 +736,9 @@ __global__ __launch_bounds__(128) void k_orientation(const float* __restrict__ i
         haar_xy(img, w, h, r + j * s, c + i * s, 4 * s, &hx, &hy);
         const float rx = gauss * hx;
         const float ry = gauss * hy;
-        s_rx[tid] = rx;
-        s_ry[tid] = ry;
-        s_rz[tid] = get_angle(rx, ry);
+        s_rx[slot] = rx;
+        s_ry[slot] = ry;
+        s_rz[slot] = get_angle(rx, ry);
     }
     __syncthreads();
     if (tid < 42) {
@@ -621,6 +778,7 @@ __global__ __launch_bounds__(128) void k_orientation(const float* __restrict__ i
     if (tid == 0) orientation[ip] = get_angle(s_sx[0], s_sy[0]);
     __syncthreads();                                 // the shared arrays are reused by the next point
     }
+    }
 }
 
 // -------------------------------------------------------------- descriptor
@@ -634,7 +792,8 @@ __global__ __launch_bounds__(128) void k_orientation(const float* __restrict__ i
 __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ img, int width, int height,
                                                     const float2* __restrict__ pos, const float* __restrict__ scale,
                                                     const float* __restrict__ orientation,
-                                                    const int* __restrict__ counts, float* __restrict__ desc)
+                                                    const int* __restrict__ counts, float* __restrict__ desc,
+                                                    NmsTable nms, const int* __restrict__ rowoff)
 {
     __shared__ float s_d[16][4][81];
     __shared__ float s_len[16];
@@ -646,19 +805,32 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
         orientation += f * kMaxIpts;
         desc += f * kMaxIpts * 64;
         counts += f * 2;
+        rowoff += f * nms.rows;
     }
     const int tid = threadIdx.x;
     const int n_ipts = counts[0];
-    for (int ip = blockIdx.x; ip < n_ipts; ip += gridDim.x) {      // uniform over the block
+    // which points the block handles: see PointWalk (uniform over the block)
+    const PointWalk walk = point_walk(nms, rowoff, n_ipts);
+    for (int li = 0; li < kNms; li++) {
+    int ip_lo, ip_hi;
+    walk_range(walk, li, &ip_lo, &ip_hi);
+    for (int ip = ip_lo; ip < ip_hi; ip += walk.stride) {
     const float x = mif_roundf(pos[ip].x);
     const float y = mif_roundf(pos[ip].y);
     float si, co;
     mif_sincosf(orientation[ip], &si, &co);
     const float thScale = scale[ip];
     const int hs = (int)(2 * mif_roundf(thScale));
+    // The 81 samples of a sub-region form a 9 x 9 grid (k, l) rotated by the orientation: k moves a
+    // sample by thScale (co, si) pixels, l by thScale (-si, co). Consecutive threads take consecutive
+    // samples along the axis that changes the image COLUMN more, so that the lanes of a wave read along
+    // image rows rather than down a column (a cache line per lane). Which thread evaluates a sample does
+    // not enter the result: it lands in the sample's own slot s_d[.][.][tha].
+    const bool k_fast = mif_fabsf(co) >= mif_fabsf(si);
     for (int item = tid; item < 16 * 81; item += 256) {
         const int bIdx = item / 81;
-        const int tha = item - bIdx * 81;
+        const int t81 = item - bIdx * 81;
+        const int tha = k_fast ? (t81 % 9) * 9 + t81 / 9 : t81;
         const int j = c_tab_j[bIdx];
         const int i = c_tab_i[bIdx];
         const float ix = (float)(i + 5);
@@ -722,6 +894,7 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
         desc[(size_t)ip * 64 + tid] = mine * lengthOfDescriptor;
     }
     __syncthreads();                                 // the shared arrays are reused by the next point
+    }
     }
 }
 
@@ -878,6 +1051,13 @@ int surf_create_impl(mif_surf* s)
         if (i * i + j * j < 36) items[k++] = (unsigned char)id;
     }
     MIF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_orient_item), items, sizeof(items)));
+    unsigned char slots[109];
+    for (int t = 0; t < 109; t++) slots[t] = (unsigned char)t;
+    std::sort(slots, slots + 109, [&](unsigned char a, unsigned char b) {
+        const int ja = items[a] % 13, jb = items[b] % 13;          // row of the grid
+        return ja != jb ? ja < jb : items[a] < items[b];           // then column (id / 13)
+    });
+    MIF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_orient_slot), slots, sizeof(slots)));
     return MIF_OK;
 }
 
@@ -902,9 +1082,20 @@ int surf_enqueue(mif_surf* s, const void* d_pixels, int nf)
     else
         hipLaunchKernelGGL(k_scan_cols_serial, dim3((w + 63) / 64, nf), dim3(64), 0, st, s->integral, w, h);
     if (tm) MIF_HIP(hipEventRecord(s->ev_stage[1], st));
-    const int lw = std::max(s->tab.l[0].w, 1), lh = std::max(s->tab.l[0].h, 1);
-    hipLaunchKernelGGL(k_hessian, dim3((lw + 15) / 16, (lh + 15) / 16, kLayers * nf), dim3(256), 0, st,
-                       (const float*)s->integral, w, h, s->tab, s->responses, s->laplacians, s->pool);
+    // the first octave's four layers from a window staged in LDS where they share one output grid (they do
+    // for every image the reference's layer table is built for), the rest straight from memory
+    static const bool no_staged = getenv("MIF_SURF_NO_STAGED_HESSIAN") != nullptr;      // A/B switch
+    bool staged = !no_staged && s->tab.l[0].w > 0 && s->tab.l[0].h > 0;
+    for (int i = 0; i < kHessFirstLayers; i++)
+        staged = staged && s->tab.l[i].w == s->tab.l[0].w && s->tab.l[i].h == s->tab.l[0].h &&
+                 s->tab.l[i].step == kSampleStep && s->tab.l[i].filter <= kHessMaxFilter;
+    const int first = staged ? kHessFirstLayers : 0;
+    if (staged)
+        hipLaunchKernelGGL(k_hessian_staged, dim3((s->tab.l[0].w + 15) / 16, (s->tab.l[0].h + 15) / 16, nf), dim3(256), 0,
+                           st, (const float*)s->integral, w, h, s->tab, s->responses, s->laplacians, s->pool);
+    const int lw = std::max(s->tab.l[first].w, 1), lh = std::max(s->tab.l[first].h, 1);
+    hipLaunchKernelGGL(k_hessian, dim3((lw + 15) / 16, (lh + 15) / 16, (kLayers - first) * nf), dim3(256), 0, st,
+                       (const float*)s->integral, w, h, s->tab, s->responses, s->laplacians, s->pool, first);
     if (tm) MIF_HIP(hipEventRecord(s->ev_stage[2], st));
     hipLaunchKernelGGL(k_nms_mark, dim3(s->nms.words, s->nms_max_h, kNms * nf), dim3(64), 0, st, s->tab, s->nms,
                        (const float*)s->responses, (const int*)s->laplacians, kThres, s->mask, s->rowcnt, s->pool);
@@ -916,16 +1107,21 @@ int surf_enqueue(mif_surf* s, const void* d_pixels, int nf)
                            (const unsigned long long*)s->mask, (const int*)s->rowcnt, (const int*)s->rowoff, kMaxIpts,
                            s->pos, s->scale, s->lap, s->pool);
     // The point lists hold up to 8000 points per frame and a typical frame a few thousand: the blocks of a
-    // frame walk its list with the grid's stride. One frame gets a block per two list slots, batches get
-    // fewer blocks per frame so that the launch stays at a few thousand blocks.
-    const int per_frame = std::max(64, std::min(kMaxIpts / 2, 16384 / nf));
+    // frame walk its list (see PointWalk). One frame gets a block per two list slots, batches get fewer
+    // blocks per frame (64 frames: 1024, measured against 256 / 2048 / 4000: descriptor 3.00 ms against
+    // 3.16 / 3.15 / 3.42; few blocks per frame keep many frames in flight, whose bands of the integral
+    // image then compete for the L2).
+    static const int per_frame_env = getenv("MIF_SURF_BLOCKS") ? atoi(getenv("MIF_SURF_BLOCKS")) : 0;   // tuning override
+    const int per_frame = per_frame_env > 0 ? 8 * ((per_frame_env + 7) / 8)
+                                            : 8 * ((std::max(64, std::min(kMaxIpts / 2, 65536 / nf)) + 7) / 8);
     if (tm) MIF_HIP(hipEventRecord(s->ev_stage[3], st));
     hipLaunchKernelGGL(k_orientation, dim3(per_frame, nf), dim3(128), 0, st, (const float*)s->integral, w, h,
-                       (const float2*)s->pos, (const float*)s->scale, (const int*)s->counts, s->orient);
+                       (const float2*)s->pos, (const float*)s->scale, (const int*)s->counts, s->orient, s->nms,
+                       (const int*)s->rowoff);
     if (tm) MIF_HIP(hipEventRecord(s->ev_stage[4], st));
     hipLaunchKernelGGL(k_descriptor, dim3(per_frame, nf), dim3(256), 0, st, (const float*)s->integral, w, h,
                        (const float2*)s->pos, (const float*)s->scale, (const float*)s->orient, (const int*)s->counts,
-                       s->desc);
+                       s->desc, s->nms, (const int*)s->rowoff);
     hipLaunchKernelGGL(k_pack_points, dim3(64, nf), dim3(256), 0, st, (const float2*)s->pos, (const float*)s->scale,
                        (const float*)s->orient, (const int*)s->lap, (const float*)s->desc, (const int*)s->counts,
                        reinterpret_cast<uint32_t*>(s->packed));
