@@ -647,28 +647,57 @@ __global__ __launch_bounds__(256) void k_nms_emit(LayerTable tab, NmsTable nms, 
 // every scale (one contiguous eighth of the whole list per XCD left the XCD with the coarse points,
 // whose windows are far larger, working long after the others: 6.19 instead of 3.39 ms), and its L2
 // holds one band of the image.
+static_assert(kNms == 6, "PointWalk names the launches' first points one by one");
 struct PointWalk {
-    int start[kNms + 1];             // first point of every launch in the frame's list; [kNms] = the count
+    // first point of every launch in the frame's list and the end of the list: separate members, not an
+    // array (an array indexed by the launch would live in scratch memory); all read up front, side by side
+    int s0, s1, s2, s3, s4, s5, s6;
     int xcd, first, stride;          // this block: XCD, position among the XCD's blocks, their number
 };
 
 __device__ __forceinline__ PointWalk point_walk(const NmsTable& nms, const int* __restrict__ rowoff, int n)
 {
     PointWalk W;
-#pragma unroll
-    for (int i = 0; i < kNms; i++) W.start[i] = (nms.n[i].row0 < nms.rows) ? min(rowoff[nms.n[i].row0], n) : n;
-    W.start[kNms] = n;
+    auto start = [&](int i) { return nms.n[i].row0 < nms.rows ? min(rowoff[nms.n[i].row0], n) : n; };
+    W.s0 = start(0); W.s1 = start(1); W.s2 = start(2); W.s3 = start(3); W.s4 = start(4); W.s5 = start(5);
+    W.s6 = n;
     W.xcd = (int)(blockIdx.x & 7u);
     W.first = (int)(blockIdx.x >> 3);
     W.stride = (int)(gridDim.x >> 3);
     return W;
 }
-// points of launch i this block handles: lo + first, lo + first + stride, ... below hi
+// True when the block cannot get a point of a list of n points, judged from n alone (a launch holds at
+// most n points, an XCD's share at most ceil(n / 8)): the grid is sized for the list's capacity, so for a
+// frame with few points most blocks leave here, before anything else is read.
+__device__ __forceinline__ bool walk_idle(int n)
+{
+    const int stride = (int)(gridDim.x >> 3), first = (int)(blockIdx.x >> 3);
+    const int most = (n + 7) >> 3;
+    bool idle = true;
+#pragma unroll
+    for (int i = 0; i < kNms; i++) {
+        int j = first - i * (stride / kNms);
+        if (j < 0) j += stride;
+        idle = idle && j >= most;
+    }
+    return idle;
+}
+__device__ __forceinline__ int launch_start(const PointWalk& W, int i)
+{
+    return i == 0 ? W.s0 : i == 1 ? W.s1 : i == 2 ? W.s2 : i == 3 ? W.s3 : i == 4 ? W.s4 : i == 5 ? W.s5 : W.s6;
+}
+// points of launch i this block handles: lo, lo + stride, ... below hi
 __device__ __forceinline__ void walk_range(const PointWalk& W, int i, int* lo, int* hi)
 {
-    const int len = W.start[i + 1] - W.start[i];
-    *lo = W.start[i] + (int)((long long)W.xcd * len / 8) + W.first;
-    *hi = W.start[i] + (int)((long long)(W.xcd + 1) * len / 8);
+    const int s0 = launch_start(W, i);
+    const int len = launch_start(W, i + 1) - s0;
+    // the launches start at different blocks of the XCD, so that a frame with few points (fewer per
+    // launch and XCD than the XCD has blocks) still spreads them over many blocks instead of giving the
+    // first blocks one point of every launch
+    int j = W.first - i * (W.stride / kNms);
+    if (j < 0) j += W.stride;
+    *lo = s0 + (int)((long long)W.xcd * len / 8) + j;
+    *hi = s0 + (int)((long long)(W.xcd + 1) * len / 8);
 }
 
 // atan of a non-negative (possibly infinite or NaN) argument
@@ -718,6 +747,7 @@ __global__ __launch_bounds__(128) void k_orientation(const float* __restrict__ i
     const int tid = threadIdx.x;
     const int n_ipts = counts[0];
     // which points the block handles: see PointWalk (uniform over the block)
+    if (walk_idle(n_ipts)) return;
     const PointWalk walk = point_walk(nms, rowoff, n_ipts);
     for (int li = 0; li < kNms; li++) {
     int ip_lo, ip_hi;
@@ -810,6 +840,7 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
     const int tid = threadIdx.x;
     const int n_ipts = counts[0];
     // which points the block handles: see PointWalk (uniform over the block)
+    if (walk_idle(n_ipts)) return;
     const PointWalk walk = point_walk(nms, rowoff, n_ipts);
     for (int li = 0; li < kNms; li++) {
     int ip_lo, ip_hi;
@@ -826,7 +857,11 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
     // samples along the axis that changes the image COLUMN more, so that the lanes of a wave read along
     // image rows rather than down a column (a cache line per lane). Which thread evaluates a sample does
     // not enter the result: it lands in the sample's own slot s_d[.][.][tha].
+#ifdef MIF_SURF_NO_KFAST
+    const bool k_fast = false;
+#else
     const bool k_fast = mif_fabsf(co) >= mif_fabsf(si);
+#endif
     for (int item = tid; item < 16 * 81; item += 256) {
         const int bIdx = item / 81;
         const int t81 = item - bIdx * 81;

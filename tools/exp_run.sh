@@ -20,9 +20,8 @@ pmc() { # name, counters (quoted), command...
   python3 tools/pmc_summary.py $O/$name/q_counter_collection.csv > $O/$name.txt
   grep -v "rocclr\|at::native" $O/$name.txt | cut -c1-400
 }
-SURF="python3 $R/tools/bench_surf.py --skip-single --batch 64 --steps 5"
-timeout -k 10 300 python3 -u -m pytest tests/test_surf_gpu.py -x -q --timeout 200 --timeout-method thread > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }
-tail -1 $O/tests.log
-export MIF_SURF_BLOCKS=1024
-trace surf_lane X=1 -- $SURF &&
-trace surf_waverows MIF_SURF_WAVE_ROWS=1 -- $SURF
+SINGLE="python3 $R/tools/exp_surf_single.py box.pgm"
+trace single_new X=1 -- $SINGLE &&
+trace single_nokfast MIF_LIBRARY=$R/gpurun_exp/surf_nokfast.so -- $SINGLE &&
+trace single_scene X=1 -- python3 $R/tools/exp_surf_single.py scene.pgm &&
+trace single_scene_base MIF_LIBRARY=$R/gpurun_exp/base.so -- python3 $R/tools/exp_surf_single.py scene.pgm
