@@ -55,7 +55,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak
 # = 104 B. Reported as `alg_unfused`; the roofline fraction itself uses what the fused launches have to
 # move (min_bytes_per_frame), so that it is a utilisation and stays below 1.
 ALG_UNFUSED_BYTES_PER_PX_OCTAVE = 104.0
-BLUR_TRAFFIC_FILE = os.path.join("profiles", "r02_blur_traffic.json")
+BLUR_TRAFFIC_FILE = os.path.join("profiles", "r03_blur_traffic.json")
 SURF_INTEGRAL_BYTES_PER_PX = 16.0   # row scan r4 + w4, column scan r4 + w4 (the reference moves 32 with its transposes)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 DEMO_DIR = os.path.join(ROOT, "object_detection_amd", "cpp", "build")
@@ -89,7 +89,7 @@ def parse_args(argv=None):
                          "start in pinned host memory, summaries end there); for profiling that schedule")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the value_host_to_host measurement")
     ap.add_argument("--no-two-streams-leg", action="store_true", help="skip the value_two_streams measurement")
-    ap.add_argument("--host-steps", type=int, default=5, help="timed steps of the host-to-host legs")
+    ap.add_argument("--host-steps", type=int, default=8, help="timed steps of the host-to-host legs")
     ap.add_argument("--no-feature-leg", action="store_true", help="skip the value_host_to_host_features measurement")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the `configs` block (SIFT / SURF box-scene pair, SURF 1080p batch, 4K batch)")
@@ -373,10 +373,12 @@ class FeatureDownload:
     descriptors in the caller's memory) for whole batches: after the feature phase of batch k the rows of all
     its frames are packed back to back on the device (mif_sift_pack_results) and their offsets downloaded
     on the compute stream (2 KB); once the host knows the row count it enqueues three copies of exactly
-    that many rows into pinned host memory on a download stream, which run beside the next batch's
-    kernels. Device staging and pinned buffers exist twice and alternate; the packing of batch k + 2
-    waits (on the device) for the download of batch k. The download stream never waits for an event, so
-    it cannot hold up a stream that shares its hardware queue."""
+    that many rows into pinned host memory on a download stream, which run beside the next batches'
+    kernels. The host asks for the row count of batch k - 2 when it has enqueued batch k, so it does not
+    wait in practice and keeps enqueuing uploads and kernels a batch ahead of the GPU. Device staging and
+    pinned buffers exist twice and alternate; the packing of batch k waits (on the device) for the
+    download of batch k - 2. The download stream never waits for an event, so it cannot hold up a stream
+    that shares its hardware queue."""
 
     def __init__(self, pipe, torch, device, rows_per_frame):
         B = pipe.B
@@ -396,12 +398,15 @@ class FeatureDownload:
         self.ev_done = [None, None]
         self.rows = [0, 0]
         self.bytes = 0
-        self.pending = None                     # batch whose rows are packed but not yet on their way
+        self.pending = []                       # batches whose rows are packed but not yet on their way
 
     def after_step(self):
-        """Call right after Pipeline.step(): packs the batch just enqueued and sends the previous one."""
+        """Call right after Pipeline.step(): sends the batch before the previous one on its way and packs
+        the batch just enqueued."""
         k = self.pipe.step_no - 1
         p = k % 2
+        if len(self.pending) >= 2:
+            self.fetch()                        # batch k - 2: its staging arrays are the ones batch k packs into
         cs = self.pipe.mstream                  # the compute stream
         if self.ev_done[p] is not None:
             cs.wait_event(self.ev_done[p])      # the staging arrays are free again
@@ -410,13 +415,13 @@ class FeatureDownload:
         with self.torch.cuda.stream(cs):
             self.h_off[p].copy_(self.d_off[p], non_blocking=True)
         self.ev_off[p].record(cs)
-        self.fetch()
-        self.pending = k
+        self.pending.append(k)
 
     def fetch(self):
-        if self.pending is None:
+        """Enqueues the download of the oldest packed batch."""
+        if not self.pending:
             return
-        p, B = self.pending % 2, self.B
+        p, B = self.pending.pop(0) % 2, self.B
         self.ev_off[p].synchronize()            # the batch's kernels have finished; the next one's are queued
         n, held = int(self.h_off[p][B]), int(self.h_off[p][B + 1])
         if held > n:
@@ -430,10 +435,10 @@ class FeatureDownload:
         self.ev_done[p] = ev
         self.rows[p] = n
         self.bytes += n * (16 + 4 + 512) + (B + 2) * 4
-        self.pending = None
 
     def finish(self):
-        self.fetch()
+        while self.pending:
+            self.fetch()
         self.dstream.synchronize()
 
     def frame(self, parity, f):
@@ -478,16 +483,16 @@ def cpu_baseline(frames, budget_s, match=True):
                          "extract + match vs previous frame" if match else "extraction only")}
 
 
-def checker_frame1(frames, match=True):
-    """What the CPU checker gets for frame 1 of the batch (matched against frame 0): per-octave counts,
-    mask of good matches and the nearest database row of every query."""
+def checker_frame(frames, f=1, match=True):
+    """What the CPU checker gets for frame f >= 1 of the batch (matched against frame f - 1): per-octave
+    counts, the features, the mask of good matches and the nearest database row of every query."""
     import oracle_lib as orc
     import object_detection_amd as oda
     n, h, w = frames.shape[:3]
     S = orc.SiftOracle(w, h, 1 if frames.ndim == 3 else frames.shape[3])
-    S.run(frames[0])
+    S.run(frames[f - 1])
     des0 = S.all_features()[3]
-    rc = S.run(frames[1])
+    rc = S.run(frames[f])
     counts = [S.count(o) for o in range(3)]
     des1 = S.all_features()[3]
     out = {"status": rc, "counts": counts, "features": S.all_features()}
@@ -498,17 +503,17 @@ def checker_frame1(frames, match=True):
     return out
 
 
-def compare_frame1(pipe, want, match=True):
-    """Frame 1 of the batch extracted last against `want` (checker_frame1). Returns (ok, details)."""
+def compare_frame(pipe, want, match=True, f=1):
+    """Frame f of the batch extracted last against `want` (checker_frame). Returns (ok, details)."""
     p = pipe.last()
-    status, counts, _ = pipe.h[p].read_counts(1)
-    det = {"frame": 1, "keypoints": counts, "keypoints_checker": want["counts"]}
+    status, counts, _ = pipe.h[p].read_counts(f)
+    det = {"frame": f, "keypoints": counts, "keypoints_checker": want["counts"]}
     ok = counts == want["counts"] and status == want["status"]
     if match and "keep" in want:
         nq = sum(counts)
-        summ = pipe.summ[p][1].cpu().numpy()
-        good = pipe.good[p][1, :nq].cpu().numpy().astype(bool)
-        idx = pipe.idx[p][1, :nq, 0].cpu().numpy()
+        summ = pipe.summ[p][f].cpu().numpy()
+        good = pipe.good[p][f, :nq].cpu().numpy().astype(bool)
+        idx = pipe.idx[p][f, :nq, 0].cpu().numpy()
         keep = want["keep"]
         same_rows = len(keep) == nq
         det.update(good_matches=int(summ[0]), good_matches_checker=int(keep.sum()))
@@ -1068,10 +1073,17 @@ def main():
     counts = pipe.h[pipe.last()].read_counts(args.batch - 1)
 
     # the same frames through the CPU checker: frame 1 of the last batch must agree with it
-    verified, verify_detail, want = None, None, None
+    # (frames 1, batch / 2 and batch - 1 of the headline run; the later legs re-check frame 1)
+    verified, verify_detail, want, verified_frames = None, None, None, None
     if not args.no_verify and rank == 0 and args.batch >= 2:
-        want = checker_frame1(frames_np, match=not args.no_match)
-        verified, verify_detail = compare_frame1(pipe, want, match=not args.no_match)
+        want = checker_frame(frames_np, 1, match=not args.no_match)
+        verified, verify_detail = compare_frame(pipe, want, match=not args.no_match)
+        verified_frames = {1: verified}
+        for f in sorted({max(1, args.batch // 2), args.batch - 1} - {1}):
+            ok_f, _ = compare_frame(pipe, checker_frame(frames_np, f, match=not args.no_match),
+                                    match=not args.no_match, f=f)
+            verified_frames[f] = ok_f
+            verified = bool(verified and ok_f)
 
     # PCIe-inclusive rate: the same step fed from pinned host memory, summaries back on the host
     host_leg = None
@@ -1084,7 +1096,7 @@ def main():
                     "window": "pinned host frames -> upload -> extract + match -> match summaries in pinned "
                               "host memory"}
         if want is not None:
-            ok_h, _ = compare_frame1(pipe, want, match=True)
+            ok_h, _ = compare_frame(pipe, want, match=True)
             host_leg["verified"] = ok_h
             verified = bool(verified and ok_h)
 
@@ -1112,7 +1124,7 @@ def main():
                                  "descriptors (packed per batch, mif_sift_pack_results) and match summaries in "
                                  "pinned host memory"}
         if want is not None:
-            ok_f, _ = compare_frame1(pipe, want, match=True)
+            ok_f, _ = compare_frame(pipe, want, match=True)
             kp_h, ori_h, des_h = fd.frame(pipe.last(), 1)
             kp_w, _, ori_w, des_w = want["features"]
             ok_f = bool(ok_f and np.array_equal(kp_h.view(np.uint32), kp_w.view(np.uint32)) and
@@ -1136,7 +1148,7 @@ def main():
                            "window": "frames resident in HBM; two handles on a stream each, a matcher each, "
                                      "batches side by side"}
             if want is not None:
-                ok_t, _ = compare_frame1(pipe, want, match=True)
+                ok_t, _ = compare_frame(pipe, want, match=True)
                 two_streams["verified"] = ok_t
                 verified = bool(verified and ok_t)
         except RuntimeError as exc:                      # e.g. no memory for the second matcher
@@ -1211,6 +1223,7 @@ def main():
             "per_rank_ms_per_step": per_rank_ms,
             "value_two_streams": two_streams,
             "verified": verified,
+            "verified_frames": verified_frames,
             "verify_detail": verify_detail,
         }
     else:

@@ -3,7 +3,7 @@
 # and of the big matcher search, the memory-traffic counter passes and the SQ / cache counter passes
 # (each counter pass is a run of its own). Every GPU step runs under its own time limit; the script
 # stops at the first step that fails.
-# usage (from the repo root): bash tools/profile_round.sh r02 [steps...]   steps: bench trace match pmc sq
+# usage (from the repo root): bash tools/profile_round.sh r03 [steps...]   steps: bench trace match pmc sq surf 4k micro
 # Writes under gpurun_out/<tag>/; copy what is to be kept into profiles/.
 set -e -o pipefail
 TAG=${1:-r02}
@@ -15,7 +15,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
 # the frame pipeline alone: no matcher block, no host-to-host leg, no CPU legs
-PIPE="--no-cpu-baseline --no-verify --no-host-leg --no-two-streams-leg --match-rows 0"
+PIPE="--no-cpu-baseline --no-verify --no-host-leg --no-two-streams-leg --no-configs --match-rows 0"
 has() { [[ " $STEPS " == *" $1 "* ]]; }
 
 if has bench; then
@@ -70,5 +70,38 @@ if has sq; then
         --output-format csv -d "$OUT/pmc_l2" -o q -- \
         python "$ROOT/bench.py" $PIPE --batch 512 --steps 1 --warmup 1 > "$OUT/pmc_l2.log" 2>&1
     python "$ROOT/tools/pmc_summary.py" "$OUT"/pmc_l2/q_counter_collection.csv > "$OUT/l2_counters_batch512.txt"
+fi
+if has surf; then
+    echo "[surf] kernel trace and counters of the SURF batch (64 frames 1080p BGR, BASELINE.json configs[1])"
+    SURF="python $ROOT/tools/bench_surf.py --skip-single --batch 64 --steps 5"
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_surf" -o t -- $SURF > "$OUT/surf_bench.json" 2> "$OUT/surf_trace.err"
+    cp "$OUT"/trace_surf/t_kernel_stats.csv "$OUT/surf_kernel_stats.csv"
+    python "$ROOT/tools/kstats.py" "$OUT/surf_kernel_stats.csv" 7 12
+    timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVES \
+        --output-format csv -d "$OUT/pmc_surf_sq" -o q -- $SURF > "$OUT/pmc_surf_sq.log" 2>&1
+    timeout -s KILL 120 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE TCC_HIT_sum TCC_MISS_sum \
+        --output-format csv -d "$OUT/pmc_surf_mem" -o q -- $SURF > "$OUT/pmc_surf_mem.log" 2>&1
+    timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_surf_fetch" -o q -- $SURF > "$OUT/pmc_surf_fetch.log" 2>&1
+    timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_surf_write" -o q -- $SURF > "$OUT/pmc_surf_write.log" 2>&1
+    for c in sq mem fetch write; do
+        python "$ROOT/tools/pmc_summary.py" "$OUT"/pmc_surf_$c/q_counter_collection.csv | grep -v "rocclr\|at::native"
+    done > "$OUT/surf_counters_batch64.txt"
+    cat "$OUT/surf_counters_batch64.txt" | cut -c1-300
+fi
+
+if has 4k; then
+    echo "[4k] kernel trace of the 4K single-channel batch (64 frames, extraction only, BASELINE.json configs[3])"
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_4k" -o t -- \
+        python "$ROOT/bench.py" $PIPE --width 3840 --height 2160 --channels 1 --no-match --batch 64 --steps 5 --warmup 2 > "$OUT/bench_4k.json" 2> "$OUT/trace_4k.err"
+    cp "$OUT"/trace_4k/t_kernel_stats.csv "$OUT/4k_kernel_stats.csv"
+    python "$ROOT/tools/kstats.py" "$OUT/4k_kernel_stats.csv" 7 14
+fi
+
+if has micro; then
+    echo "[micro] vector issue rates and the host link"
+    timeout -k 10 120 "$ROOT/tools/micro/valu_rate" > "$OUT/valu_rate.txt" 2>&1
+    cat "$OUT/valu_rate.txt"
+    timeout -k 10 120 "$ROOT/tools/micro/h2d_bw" > "$OUT/h2d_bw.txt" 2>&1
+    tail -20 "$OUT/h2d_bw.txt"
 fi
 echo "[done] $STEPS"
