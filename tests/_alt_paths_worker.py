@@ -28,6 +28,24 @@ def main(out):
             res["%s_kp%d" % (tag, f)] = feat.keypoints
             res["%s_ori%d" % (tag, f)] = feat.orientations
             res["%s_des%d" % (tag, f)] = feat.descriptors
+    # a BGR batch whose width is a multiple of four (the level-0 blur then fetches four pixels per load)
+    frames = [blob_image(332, 216, seed=13 + i, channels=3, shift=(2 * i, i)) for i in range(3)]
+    px = torch.from_numpy(np.stack(frames)).to(dev)
+    ex = oda.SiftExtractor(332, 216, 3, batch=3)
+    ex.enqueue(px.data_ptr(), 3)
+    for f in range(3):
+        rc, feat = ex.copy_results(f)
+        res["bgr4_rc%d" % f] = np.int32(rc)
+        res["bgr4_kp%d" % f] = feat.keypoints
+        res["bgr4_des%d" % f] = feat.descriptors
+    # SURF: points and the first and last response layer of a small BGR frame
+    sx = oda.SurfExtractor(332, 216, 3)
+    pts, raw = sx.run(frames[0])
+    res["surf_points"] = pts.view(np.uint8)
+    res["surf_raw"] = np.int32(raw)
+    for layer in (0, 3, 7):
+        r, l = sx.layer(layer)
+        res["surf_resp%d" % layer], res["surf_lap%d" % layer] = r, l
     # a batch large enough for the screening passes (16 pairs of 1500 x 1400 rows)
     P, cap = 16, 1500
     Q = torch.zeros((P, cap, 128), dtype=torch.float32, device=dev)

@@ -44,6 +44,19 @@ def test_descriptor_window_loops(tmp_path):
         assert ref[k].shape == alt[k].shape and ref[k].tobytes() == alt[k].tobytes(), k
 
 
+def test_staging_and_surf_switches(tmp_path):
+    """MIF_NO_WIDE_STAGING=1 (a BGR frame fetched pixel by pixel instead of four pixels per load) and
+    MIF_SURF_NO_STAGED_HESSIAN=1 (all Hessian layers straight from memory) with another grid for the SURF
+    point kernels (MIF_SURF_BLOCKS): the default's bits."""
+    ref = _run(tmp_path, "default", {})
+    assert any(k.startswith("surf_") for k in ref.files)
+    alt = _run(tmp_path, "plain", {"MIF_NO_WIDE_STAGING": "1", "MIF_SURF_NO_STAGED_HESSIAN": "1",
+                                   "MIF_SURF_BLOCKS": "72"})
+    assert sorted(ref.files) == sorted(alt.files)
+    for k in ref.files:
+        assert ref[k].shape == alt[k].shape and ref[k].tobytes() == alt[k].tobytes(), k
+
+
 @pytest.mark.parametrize("mask", ["0", "7"])
 def test_scale_space_levels_singly_or_in_pairs(tmp_path, mask):
     """MIF_BLUR_PAIRS selects which levels of an octave are built two per launch (default: levels 0 and 1
