@@ -993,7 +993,8 @@ def main():
                 dev_buf=[torch.empty_like(frames), frames],
                 cstreams=[torch.cuda.Stream(device=device) for _ in range(ncopy)],
                 cuts=[args.batch * i // ncopy for i in range(ncopy + 1)],
-                host_summ=[torch.empty((args.batch, 2), dtype=torch.int32).pin_memory() for _ in range(2)])
+                host_summ=[torch.empty((args.batch, 2), dtype=torch.int32).pin_memory() for _ in range(2)],
+                marks=[])
         hs = host_state
         k = pipe.step_no
         hk = pipe.h[k % 2]
@@ -1007,10 +1008,24 @@ def main():
         for cs in hs["cstreams"]:
             pipe._wait(hk.stream(), cs.cuda_stream)
         pipe.step(hs["dev_buf"][k % 2].data_ptr())
+        if not pipe.split:
+            # end of this batch's feature phase on the one compute stream: the distance between two such
+            # marks is a step of the filled pipeline
+            mark = torch.cuda.Event(enable_timing=True)
+            mark.record(pipe.mstream)
+            hs["marks"].append(mark)
         if k >= 1 and pipe.match and not pipe.serial:
             # the matcher of batch k - 1 has just been enqueued: its summaries go back to the host behind it
             with torch.cuda.stream(pipe.mstream):
                 hs["host_summ"][(k - 1) % 2].copy_(pipe.summ[(k - 1) % 2], non_blocking=True)
+
+    def steady_ms(steps):
+        """ms per step between the end of the first and of the last timed step of the leg that has just run
+        (the first step's upload has nothing to hide behind; a long sequence pays it once)."""
+        marks = host_state.get("marks", [])[-steps:]
+        if steps < 3 or len(marks) < steps:
+            return None
+        return marks[0].elapsed_time(marks[-1]) / (steps - 1)
 
     own_seconds = {}
 
@@ -1095,6 +1110,10 @@ def main():
                     "upload_GBps_per_gpu": args.batch * frames_np[0].nbytes * args.host_steps / dt_host / 1e9,
                     "window": "pinned host frames -> upload -> extract + match -> match summaries in pinned "
                               "host memory"}
+        st = steady_ms(args.host_steps)
+        if st:
+            host_leg["ms_per_step_filled_pipeline"] = st
+            host_leg["value_filled_pipeline"] = args.batch * world / (st * 1e-3)
         if want is not None:
             ok_h, _ = compare_frame(pipe, want, match=True)
             host_leg["verified"] = ok_h
@@ -1123,6 +1142,10 @@ def main():
                        "window": "pinned host frames -> upload -> extract + match -> keypoints, orientations, "
                                  "descriptors (packed per batch, mif_sift_pack_results) and match summaries in "
                                  "pinned host memory"}
+        st = steady_ms(args.host_steps)
+        if st:
+            feature_leg["ms_per_step_filled_pipeline"] = st
+            feature_leg["value_filled_pipeline"] = args.batch * world / (st * 1e-3)
         if want is not None:
             ok_f, _ = compare_frame(pipe, want, match=True)
             kp_h, ori_h, des_h = fd.frame(pipe.last(), 1)

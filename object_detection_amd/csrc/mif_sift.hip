@@ -1457,7 +1457,7 @@ __device__ __forceinline__ void desc_accumulate(float* __restrict__ d, float nx,
     const float nxn = mif_fabsf(nx), nyn = mif_fabsf(ny);
     const float mod = mif_fabsf(g2.x);
     // atan2(-dy, dx) from the stored atan2(dy, dx): sign bit of g2.x is set iff dy != 0
-    float th = (mif_float_to_bits(g2.x) >> 31) ? -g2.y : g2.y;
+    float th = mif_bits_to_float(mif_float_to_bits(g2.y) ^ (mif_float_to_bits(g2.x) & 0x80000000u));
     const float dnx = nx + offx, dny = ny + offy;
     // |dnx|, |dny| < 2.5 here, so the argument lies in (-1.6, 0]
     const float ww = mif_expf_bounded(-0.125f * (dnx * dnx + dny * dny));
@@ -1591,48 +1591,63 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
         for (int m = 32; m >= 1; m >>= 1) most = max(most, __shfl_xor(most, m, 64));
         most = __builtin_amdgcn_readfirstlane(most);
         for (int base = 0; base < most; base += 32, fbase += 256.0f) {
-            const int nj = min(32, most - base);
-            uint32_t mask = 0;
+            const int nj = __builtin_amdgcn_readfirstlane(min(32, most - base));
+            // round j's bit enters at the bottom and moves up: reversed and shifted down afterwards
+            uint32_t rmask = 0;
             for (int j = 0; j < nj; j++) {
                 const float dx = fx - ptx;
                 const float dy = fy - pty;
                 const float nx = crspt * dx + srspt * dy;
                 const float ny = crspt * dy - srspt * dx;
-                const bool pass = (int)(fy <= fymax) & (int)(mif_fabsf(nx) < 1.0f) & (int)(mif_fabsf(ny) < 1.0f);
-                mask |= pass ? (1u << j) : 0u;
+                // rmask = 2 rmask + pass in one instruction: the lanes' `pass` bits are the carry-in
+                const uint64_t passed = __builtin_amdgcn_ballot_w64(fy <= fymax) &
+                                        __builtin_amdgcn_ballot_w64(mif_fabsf(nx) < 1.0f) &
+                                        __builtin_amdgcn_ballot_w64(mif_fabsf(ny) < 1.0f);
+                asm("v_addc_co_u32 %0, vcc, %1, %1, %2" : "=v"(rmask) : "v"(rmask), "s"(passed) : "vcc");
                 fx += 8.0f;
                 const bool wrap = fx > fxmax;
                 fx -= wrap ? fwx : 0.0f;
                 fy += wrap ? 1.0f : 0.0f;
             }
+            uint32_t mask = __builtin_bitreverse32(rmask) >> (32 - nj);      // nj is 1..32
             // phase 2, the gather of the next marked pixel in flight while the current one is accumulated
-            float ncx, ncy;
-            v2f gn;
-            bool nact;
-            auto decode = [&]() {
-                nact = mask != 0;
+            // (two picks used alternately: nothing is copied from "next" to "current")
+            struct Pick {
+                float cx, cy;
+                v2f g;
+                bool act;
+                uint64_t any;       // lanes of the wave with a pick (a scalar: the loop's exit test)
+            };
+            auto decode = [&](Pick& p) {
+                p.act = mask != 0;
+                p.any = __builtin_amdgcn_uicmp(mask, 0u, 33);      // 33: "not equal"; the compare's lane mask itself
                 const int j = __builtin_ctz(mask | 0x80000000u);
                 mask &= mask - 1;
-                const float fi = fbase + (float)(j << 3);
+                const float fi = __builtin_fmaf((float)j, 8.0f, fbase);      // small integers: exact
                 const float q = __builtin_floorf(__builtin_fmaf(fi, rwx, hrwx));
                 const float r = __builtin_fmaf(-q, fwx, fi);
-                ncx = r + fxmin;
-                ncy = q + fymin;
+                p.cx = r + fxmin;
+                p.cy = q + fymin;
                 const uint32_t boff = boff0 + (uint32_t)__builtin_fmaf(q, fw, r) * 8u;
                 // lanes without a marked pixel left read beyond the plane: the range check returns 0
-                gn = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, nact ? boff : 0xfffffff8u, 0, 0));
+                p.g = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, p.act ? boff : 0xfffffff8u, 0, 0));
             };
-            decode();
-            while (__any(nact)) {
-                const float cfx = ncx, cfy = ncy;
-                const v2f g = gn;
-                const bool act = nact;
-                decode();
-                const float dx = cfx - ptx;
-                const float dy = cfy - pty;
+            auto visit = [&](const Pick& p) {
+                const float dx = p.cx - ptx;
+                const float dy = p.cy - pty;
                 const float nx = crspt * dx + srspt * dy;
                 const float ny = crspt * dy - srspt * dx;
-                if (act) desc_accumulate(d, nx, ny, make_float2(g.x, g.y), offx, offy, ang);
+                if (p.act) desc_accumulate(d, nx, ny, make_float2(p.g.x, p.g.y), offx, offy, ang);
+            };
+            Pick pa, pb;
+            decode(pa);
+            for (;;) {
+                if (pa.any == 0) break;
+                decode(pb);
+                visit(pa);
+                if (pb.any == 0) break;
+                decode(pa);
+                visit(pb);
             }
         }
     } else if (wide) {

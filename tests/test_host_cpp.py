@@ -97,6 +97,32 @@ def test_surf_match_demo_against_checker(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("exe", ["demo_coopcl_sift", "demo_coopcl_Surf"])
+def test_match_demo_repeat_loop_reports_the_same_result_with_times(tmp_path, exe):
+    """`-m a b -f x -r N` repeats the pair N times on warm pipelines and adds the per-stage times to the
+    report; the matches and the outline are those of the single run."""
+    box, scene = os.path.join(GOLDEN, "box.pgm"), os.path.join(GOLDEN, "scene.pgm")
+    reps = []
+    for extra in ([], ["-r", "5"]):
+        rep = str(tmp_path / ("rep%d.json" % len(reps)))
+        out = subprocess.run([_need(exe), "-m", box, scene, "-f", "1", "-o", rep] + extra,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        reps.append(json.load(open(rep)))
+    single, timed = reps
+    assert timed["good_matches"] == single["good_matches"]
+    assert timed["scene_corners"] == single["scene_corners"]
+    t = timed["timing_ms"]
+    assert t["repeats"] == 5
+    stages = [t[k] for k in ("extract_object", "extract_scene", "convert", "match", "homography")]
+    assert all(v >= 0.0 for v in stages) and t["extract_scene"] > 0.0 and t["match"] > 0.0
+    # the stages are what a repeat consists of; its fastest run cannot take longer than the mean
+    assert 0.0 < t["total_min"] <= t["total"] * 1.0001
+    assert sum(stages) <= t["total"] * 1.05
+    assert t["total"] < 1000.0
+
+
+@pytest.mark.gpu
 def test_stream_demo_on_raw_frames(tmp_path):
     from synth import blob_image
     frames = [blob_image(320, 240, seed=5, channels=3, shift=(2 * t, t)) for t in range(4)]
