@@ -1483,9 +1483,9 @@ __device__ __forceinline__ void desc_accumulate(float* __restrict__ d, float nx,
     }
     const float tth = (float)((double)th * K_RPI);
     // th is in [0, 2 pi) now, tth in [0, 8]: the floor is the truncation, and the bin as a float is the floor
-    const float ffo = __builtin_floorf(tth);
-    const int fo0 = (int)ffo;
-    const float do0 = tth - ffo;
+    // (the fraction instruction returns tth - floor(tth), an exact difference for tth >= 0)
+    const int fo0 = (int)tth;
+    const float do0 = __builtin_amdgcn_fractf(tth);
     const int fo = fo0 & 7;             // fo0 is in 0..8; same as the reference's % 8
     d[fo * kDescStride] += (1.0f - do0) * wgt;
     d[(fo + 1) * kDescStride] += do0 * wgt;
@@ -1564,13 +1564,17 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
     // descriptor of the level's plane, whose range check makes the look-ahead of lanes that have left
     // their window harmless (they read 0 and accumulate nothing). The plane must fit a 32-bit offset.
     const bool wide = MODE != 0 && __all(wx >= 8 && hy > 0) && (size_t)w * h < ((size_t)1 << 29);
-    if (MODE == 2 && wide && __all(wx <= 128 && hy <= 128) && w < (1 << 16)) {
+    if (MODE == 2 && wide && __all(wx <= 128 && hy <= 128) && w <= (1 << 14) && (size_t)w * h <= ((size_t)1 << 24)) {
         // Two phases per 32 rounds of the walk. Phase 1 runs the walk and the cell test alone and leaves
         // bit j of `mask` set when the lane's pixel of round j passes. Phase 2 visits the set bits in
         // ascending order (the order in which the reference's work-item adds to its histogram): window
-        // pixel i = lid + 8 (base + j) lies in row i / wx and column i % wx, found as
-        // floor((i + 0.5) / wx) in float: with wx and the row at most 128 the product is off by less than
-        // 2e-5 while the exact quotient is at least 0.5 / 128 away from an integer, so the floor is exact.
+        // pixel i = lid + 8 (base + j) lies in row q = i / wx and column i % wx. The visit carries
+        // ix = i + xmin (an integer below 2^15, exact in float) and finds q as
+        // floor(ix / wx + (0.5 - xmin) / wx) in float: the exact value (i + 0.5) / wx is at least
+        // 0.5 / 128 = 3.9e-3 away from an integer (wx <= 128), and the float evaluation is off by less than
+        // 7e-4 (1 / wx and the constant rounded once each, values of at most 2^15 / 8, one rounding of
+        // the sum), so the floor is exact. Column and row then are x = ix - q wx and y = q + ymin, and
+        // the pixel's index y w + x is an integer below 2^24: all exact in float.
         // About 40 % of a window's pixels fail the test and cost the first phase only.
         const uint32_t lvl = __builtin_amdgcn_readfirstlane((uint32_t)((int)((float)(w * h) * f4.w) - w * h));
         const float2* plane = grad + lvl;
@@ -1581,10 +1585,9 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
                                                             (int)((uint32_t)(w * h) * 8u), 0x00020000);
         const float fxmax = (float)xmax, fymax = (float)ymax, fwx = (float)wx, fw = (float)w;
         const float fxmin = (float)xmin, fymin = (float)ymin;
-        const float rwx = 1.0f / fwx, hrwx = 0.5f * rwx;
-        const uint32_t boff0 = (uint32_t)(ymin * w + xmin) * 8u;
+        const float rwx = 1.0f / fwx, qoff = 0.5f * rwx - fxmin * rwx;
         float fx = (float)(xmin + lid), fy = (float)ymin;
-        float fbase = (float)lid;                           // window pixel index of this lane in round `base`
+        float fbase = (float)(xmin + lid);                  // xmin + window pixel index of this lane in round `base`
         // a lane's rounds: ceil((loops - lid) / 8); the wave runs to its longest lane
         int most = (loops - lid + 7) >> 3;
 #pragma unroll
@@ -1621,14 +1624,16 @@ __global__ __launch_bounds__(128) void k_descriptor(const float4* __restrict__ k
             auto decode = [&](Pick& p) {
                 p.act = mask != 0;
                 p.any = __builtin_amdgcn_uicmp(mask, 0u, 33);      // 33: "not equal"; the compare's lane mask itself
-                const int j = __builtin_ctz(mask | 0x80000000u);
+                // lowest set bit; -1 from an empty mask (the instruction defines it), whose lane computes
+                // a position it never uses
+                int j;
+                asm("v_ffbl_b32 %0, %1" : "=v"(j) : "v"(mask));
                 mask &= mask - 1;
-                const float fi = __builtin_fmaf((float)j, 8.0f, fbase);      // small integers: exact
-                const float q = __builtin_floorf(__builtin_fmaf(fi, rwx, hrwx));
-                const float r = __builtin_fmaf(-q, fwx, fi);
-                p.cx = r + fxmin;
+                const float ix = __builtin_fmaf((float)j, 8.0f, fbase);
+                const float q = __builtin_floorf(__builtin_fmaf(ix, rwx, qoff));
+                p.cx = __builtin_fmaf(-q, fwx, ix);
                 p.cy = q + fymin;
-                const uint32_t boff = boff0 + (uint32_t)__builtin_fmaf(q, fw, r) * 8u;
+                const uint32_t boff = (uint32_t)__builtin_fmaf(p.cy, fw, p.cx) * 8u;
                 // lanes without a marked pixel left read beyond the plane: the range check returns 0
                 p.g = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsrc, p.act ? boff : 0xfffffff8u, 0, 0));
             };
