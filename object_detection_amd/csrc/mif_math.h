@@ -77,7 +77,8 @@ MIF_HD float mif_expf_bounded(float x)
     const float n = __builtin_floorf(__builtin_fmaf(x, 1.44269504088896340736f, 0.5f));
     float r = __builtin_fmaf(n, -0.693145751953125f, x);
     r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
-    return mif_exp_poly(r) * mif_pow2i((int)n);
+    // scaling by 2^n is exact either way (n >= -126, the polynomial is near 1); ldexp is one GPU instruction
+    return __builtin_ldexpf(mif_exp_poly(r), (int)n);
 }
 
 // 2^x for |x| < 126, about 1 ulp.

@@ -1473,13 +1473,17 @@ __device__ __forceinline__ void desc_accumulate(float* __restrict__ d, float nx,
     // (float(pi) > pi) and the second at most once. (double)th >= 2 pi holds exactly
     // when th >= float(2 pi), the smallest float above 2 pi, so that test needs no
     // conversion; 64-bit operations are slow on this GPU.
-    if (th < 0.0f) {
-        th = (float)((double)th + K_M_PI2);
+    // The first round of the first loop without a branch: th + s 2 pi with s = 1.0 or 0.0 in one fused
+    // step (one rounding, like the addition; s = 0.0 leaves th as it is). Whatever else the loops do is
+    // rare and sits behind a test of the whole wave.
+    th = (float)__builtin_fma(th < 0.0f ? 1.0 : 0.0, K_M_PI2, (double)th);
+    // one unsigned comparison of the bits finds both: negative (sign bit) and >= float(2 pi) = 0x40c90fdb
+    if (__builtin_amdgcn_uicmp(mif_float_to_bits(th), 0x40c90fdbu, 35) != 0) {     // 35: unsigned >=
         if (th < 0.0f) th = (float)((double)th + K_M_PI2);
-    }
-    if (th >= 6.2831854820251465f) {
-        th = (float)((double)th - K_M_PI2);
-        if (th >= 6.2831854820251465f) th = (float)((double)th - K_M_PI2);
+        if (th >= 6.2831854820251465f) {
+            th = (float)((double)th - K_M_PI2);
+            if (th >= 6.2831854820251465f) th = (float)((double)th - K_M_PI2);
+        }
     }
     const float tth = (float)((double)th * K_RPI);
     // th is in [0, 2 pi) now, tth in [0, 8]: the floor is the truncation, and the bin as a float is the floor
