@@ -1486,11 +1486,12 @@ __device__ __forceinline__ void desc_accumulate(float* __restrict__ d, float nx,
         }
     }
     const float tth = (float)((double)th * K_RPI);
-    // th is in [0, 2 pi) now, tth in [0, 8]: the floor is the truncation, and the bin as a float is the floor
+    // th is in [0, float(2 pi)) now. The largest such float, 0x40c90fda, gives tth = 7.9999995 (its product
+    // with 4 / pi is nearer to that float than to 8), so tth lies in [0, 8), the bin (int)tth in 0..7 and the
+    // reference's `% 8` changes nothing; the truncation is the floor.
     // (the fraction instruction returns tth - floor(tth), an exact difference for tth >= 0)
-    const int fo0 = (int)tth;
+    const int fo = (int)tth;
     const float do0 = __builtin_amdgcn_fractf(tth);
-    const int fo = fo0 & 7;             // fo0 is in 0..8; same as the reference's % 8
     d[fo * kDescStride] += (1.0f - do0) * wgt;
     d[(fo + 1) * kDescStride] += do0 * wgt;
 }
