@@ -100,10 +100,11 @@ int mif_sift_enqueue(mif_sift* s, const void* d_pixels, int nframes, int want_de
  * by _features. */
 int mif_sift_enqueue_pyramid(mif_sift* s, const void* d_pixels, int nframes);
 int mif_sift_enqueue_features(mif_sift* s, int want_descriptors);
-/* Copies the descriptor rows ([capacity][128] floats) and the keypoint count of one frame of the
- * last batch into caller-owned device memory, in stream order on the handle's stream: the frame a
- * video caller matches the next batch's first frame against (SIFT/main.cpp:103-153 keeps the
- * previous frame's features on the host). */
+/* Copies the descriptor rows and the keypoint count of one frame of the last batch into caller-owned
+ * device memory (d_descriptors: room for [capacity][128] floats, 16-byte aligned; the frame's rows are
+ * written, the rest is left as it is), in stream order on the handle's stream: the frame a video
+ * caller matches the next batch's first frame against (SIFT/main.cpp:103-153 keeps the previous
+ * frame's features on the host). */
 int mif_sift_snapshot_frame(mif_sift* s, int frame, float* d_descriptors, int32_t* d_count);
 /* The readback of SIFT/sift.cpp:1889-1911 (features(), orientations() and descriptors() appended octave
  * by octave to the caller's vectors) for a whole batch: packs the rows of the first nframes frames of the

@@ -1814,6 +1814,16 @@ __global__ __launch_bounds__(256) void k_pack_rows(const float4* __restrict__ kp
         for (int i = tid; i < n * 32; i += stride) out_desc[(size_t)first * 32 + i] = desc[src * 32 + i];
 }
 
+// One frame's descriptor rows and count into a caller's buffer (mif_sift_snapshot_frame).
+__global__ __launch_bounds__(256) void k_snapshot_rows(const float4* __restrict__ desc, const int* __restrict__ count,
+                                                       int cap, float4* __restrict__ out, int* __restrict__ out_count)
+{
+    const int n = min(*count, cap);
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (int i = tid; i < n * 32; i += stride) out[i] = desc[i];
+    if (tid == 0) *out_count = *count;
+}
+
 // ------------------------------------------------------------------ host side
 
 struct OctaveBuf {
@@ -2490,11 +2500,17 @@ int mif_sift_snapshot_frame(mif_sift* s, int frame, float* d_descriptors, int32_
         mif::set_error("mif_sift_snapshot_frame: bad argument");
         return MIF_ERR_INVALID_ARGUMENT;
     }
+    if (reinterpret_cast<uintptr_t>(d_descriptors) & 15u) {
+        mif::set_error("mif_sift_snapshot_frame: the descriptor buffer must be 16-byte aligned");
+        return MIF_ERR_INVALID_ARGUMENT;
+    }
     mif::DeviceGuard guard(s->device);
-    MIF_HIP(hipMemcpyAsync(d_descriptors, s->desc + (size_t)frame * s->cap * 128, (size_t)s->cap * 128 * sizeof(float),
-                           hipMemcpyDeviceToDevice, s->stream));
-    MIF_HIP(hipMemcpyAsync(d_count, s->counts + (size_t)frame * CNT_WORDS + CNT_TOTAL, sizeof(int),
-                           hipMemcpyDeviceToDevice, s->stream));
+    // only the rows the frame holds (a few thousand of a capacity of tens of thousands)
+    hipLaunchKernelGGL(k_snapshot_rows, dim3(32), dim3(256), 0, s->stream,
+                       (const float4*)(s->desc + (size_t)frame * s->cap * 128),
+                       (const int*)(s->counts + (size_t)frame * CNT_WORDS + CNT_TOTAL), s->cap, (float4*)d_descriptors,
+                       d_count);
+    MIF_HIP(hipGetLastError());
     return MIF_OK;
 }
 

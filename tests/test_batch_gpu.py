@@ -163,6 +163,7 @@ def test_two_phase_enqueue_snapshot_and_stream_order():
     n = len(b.descriptors)
     assert int(cnt.cpu()[0]) == n and n > 0
     assert np.array_equal(snap2.cpu().numpy()[:n], b.descriptors)
+    assert np.all(snap2.cpu().numpy()[n:] == -1.0)          # only the frame's rows are written
     # the feature phase needs a pending scale space
     with pytest.raises(_lib.MifError):
         two.enqueue_features(True)
