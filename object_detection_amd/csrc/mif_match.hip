@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_match_screen(PairTable tbl, int npairs,
                                                       const float* __restrict__ dn_all,
                                                       const unsigned int* __restrict__ dnmax_all, int nsplit,
                                                       float* __restrict__ t2_all, int* __restrict__ cnt_all,
-                                                      int* __restrict__ cand_all,
+                                                      int2* __restrict__ cand_all,
                                                       unsigned int* __restrict__ work_counter)
 {
     constexpr int KS = K / 16;                 // matrix instructions per tile
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void k_match_screen(PairTable tbl, int npairs,
     // per (pair, split, query): second smallest score of the split (pass 0), candidate count and list (pass 1)
     float* __restrict__ t2s = t2_all + (size_t)z * nsplit * nq_cap;
     int* __restrict__ cnt = cnt_all + ((size_t)z * nsplit + split) * nq_cap;
-    int* __restrict__ cand = cand_all + ((size_t)z * nsplit + split) * nq_cap * kCandCap;
+    int2* __restrict__ cand = cand_all + ((size_t)z * nsplit + split) * nq_cap * kCandCap;
 
     float4 stage[NV];
     float stage_dn = 0.0f;
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void k_match_screen(PairTable tbl, int npairs,
                 while (hits != 0u) {
                     const int r = __ffs((int)hits) - 1;
                     hits &= hits - 1u;
-                    if (at < kCandCap) cand[(size_t)qi * kCandCap + at] = jbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (at < kCandCap) cand[(size_t)qi * kCandCap + at] = make_int2(jbase + (r & 3) + 8 * (r >> 2) + 4 * half, 0);
                     at++;
                 }
             }
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
                                                        const float* __restrict__ dn_all,
                                                        const unsigned int* __restrict__ dnmax_all, int nsplit,
                                                        float* __restrict__ t2_all, size_t s1_off,
-                                                       int* __restrict__ cnt_all, int* __restrict__ cand_all,
+                                                       int* __restrict__ cnt_all, int2* __restrict__ cand_all,
                                                        unsigned int* __restrict__ work_counter, int sample)
 {
     constexpr int KP = K + 16;                 // contraction length with the norm's k-step
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
     const int c_hi = min(chunks, c_lo + per);
     float* __restrict__ t2s = t2_all + (size_t)z * nsplit * nq_cap;
     int* __restrict__ cnt = cnt_all + ((size_t)z * nsplit + split) * nq_cap;
-    int* __restrict__ cand = cand_all + ((size_t)z * nsplit + split) * nq_cap * kCandCap;
+    int2* __restrict__ cand = cand_all + ((size_t)z * nsplit + split) * nq_cap * kCandCap;
 
     f32x4v stage[NV];
     float stage_dn = 0.0f;
@@ -950,11 +950,19 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
                 unsigned int hits = 0u;
 #pragma unroll
                 for (int r = 0; r < 16; r++) hits |= (acc[r] >= alim[s2] ? 1u : 0u) << r;
+                // What goes into the list with a row: the largest product of this lane's 16 rows, which is the
+                // product of the best row kept here and an upper bound for the others (k_match_rank tightens
+                // the threshold with these before it reads any row).
+                float top = mx;
                 if (!full) {                    // rows staged beyond the database end (they pass an infinite threshold)
+                    top = -kInf;
 #pragma unroll
-                    for (int r = 0; r < 16; r++)
+                    for (int r = 0; r < 16; r++) {
                         if (jbase + (r & 3) + 8 * (r >> 2) + 4 * half >= nd) hits &= ~(1u << r);
+                        else top = fmaxf(top, acc[r]);
+                    }
                 }
+                const int topbits = __float_as_int(top);
                 const int mine = __popc(hits);
                 const int other = __shfl_xor(mine, 32);
                 int at = filled[s2] + (half ? other : 0);
@@ -962,7 +970,8 @@ __global__ __launch_bounds__(64 * WV, 8 / WV) void k_match_screen2(PairTable tbl
                 while (hits != 0u) {
                     const int r = __ffs((int)hits) - 1;
                     hits &= hits - 1u;
-                    if (at < kCandCap) cand[(size_t)qi[s2] * kCandCap + at] = jbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (at < kCandCap)
+                        cand[(size_t)qi[s2] * kCandCap + at] = make_int2(jbase + (r & 3) + 8 * (r >> 2) + 4 * half, topbits);
                     at++;
                 }
             }
@@ -1110,7 +1119,7 @@ __global__ __launch_bounds__(512, 1) void k_match_screen4(PairTable tbl, int npa
                                                           const __bf16* __restrict__ dbf_all, int rows_pad,
                                                           const unsigned int* __restrict__ dnmax_all, int nsplit,
                                                           float* __restrict__ t2_all, size_t s1_off,
-                                                          int* __restrict__ cnt_all, int* __restrict__ cand_all,
+                                                          int* __restrict__ cnt_all, int2* __restrict__ cand_all,
                                                           unsigned int* __restrict__ work_counter, int sample)
 {
     constexpr int KP = K + 16;                 // contraction length with the norm's k-step
@@ -1201,7 +1210,7 @@ __global__ __launch_bounds__(512, 1) void k_match_screen4(PairTable tbl, int npa
     const int c_hi = min(chunks, c_lo + per);
     float* __restrict__ t2s = t2_all + (size_t)z * nsplit * nq_cap;
     int* __restrict__ cnt = cnt_all + ((size_t)z * nsplit + split) * nq_cap;
-    int* __restrict__ cand = cand_all + ((size_t)z * nsplit + split) * nq_cap * kCandCap;
+    int2* __restrict__ cand = cand_all + ((size_t)z * nsplit + split) * nq_cap * kCandCap;
     // the pair's bf16 image; a chunk is kChunkBytes contiguous bytes of it
     const GlobalBytes image = (GlobalBytes)(dbf_all + (size_t)z * rows_pad * KPB);
     // chunk c into buffer buf: this wave's share of the wave-wide copies, pieces first, first + step, ...
@@ -1279,11 +1288,19 @@ __global__ __launch_bounds__(512, 1) void k_match_screen4(PairTable tbl, int npa
                 unsigned int hits = 0u;
 #pragma unroll
                 for (int r = 0; r < 16; r++) hits |= (acc[r] >= alim[s2] ? 1u : 0u) << r;
+                // What goes into the list with a row: the largest product of this lane's 16 rows, which is the
+                // product of the best row kept here and an upper bound for the others (k_match_rank tightens
+                // the threshold with these before it reads any row).
+                float top = mx;
                 if (!full) {                    // rows staged beyond the database end (they pass an infinite threshold)
+                    top = -kInf;
 #pragma unroll
-                    for (int r = 0; r < 16; r++)
+                    for (int r = 0; r < 16; r++) {
                         if (jbase + (r & 3) + 8 * (r >> 2) + 4 * half >= nd) hits &= ~(1u << r);
+                        else top = fmaxf(top, acc[r]);
+                    }
                 }
+                const int topbits = __float_as_int(top);
                 const int mine = __popc(hits);
                 const int other = __shfl_xor(mine, 32);
                 int at = filled[s2] + (half ? other : 0);
@@ -1291,7 +1308,8 @@ __global__ __launch_bounds__(512, 1) void k_match_screen4(PairTable tbl, int npa
                 while (hits != 0u) {
                     const int r = __ffs((int)hits) - 1;
                     hits &= hits - 1u;
-                    if (at < kCandCap) cand[(size_t)qi[s2] * kCandCap + at] = jbase + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (at < kCandCap)
+                        cand[(size_t)qi[s2] * kCandCap + at] = make_int2(jbase + (r & 3) + 8 * (r >> 2) + 4 * half, topbits);
                     at++;
                 }
             }
@@ -1404,9 +1422,10 @@ template <bool VEC>
 __global__ __launch_bounds__(128) void k_match_rank(PairTable tbl, int nq_cap, int nd_cap, int dim, int ld,
                                                     const float* __restrict__ qn_all, const float* __restrict__ dn_all,
                                                     int nsplit, const int* __restrict__ cnt_all,
-                                                    const int* __restrict__ cand_all,
+                                                    const int2* __restrict__ cand_all,
                                                     float* __restrict__ part_s_all, int* __restrict__ part_i_all,
-                                                    OverflowEntry* __restrict__ queue, unsigned int* __restrict__ queue_count)
+                                                    OverflowEntry* __restrict__ queue, unsigned int* __restrict__ queue_count,
+                                                    const unsigned int* __restrict__ dnmax_all, int refilter)
 {
     const mif_match_pair& pr = tbl[blockIdx.y];
     const int nq = pr.d_nq ? min(*pr.d_nq, nq_cap) : nq_cap;
@@ -1432,6 +1451,39 @@ __global__ __launch_bounds__(128) void k_match_rank(PairTable tbl, int nq_cap, i
     }
     int listed = 0;
     unsigned long long deferred = 0ull, with_rows = 0ull;
+    // After a sampled first pass (refilter): the lists were filled against the looser threshold such a pass
+    // leaves and hold far more rows than the answer needs (about 160 per query at 1 M x 1 M rows with every
+    // 8th chunk sampled, spread over 32 lists). Every entry carries a bf16 product a (score s~ = |q|^2 - 2 a):
+    // the largest of the 16 rows its lane looked at in that tile, i.e. the product of the best row the lane
+    // kept there and an upper bound for the others it kept (they follow it in the list with the same
+    // value). The distinct values are therefore the products of distinct listed rows; their second largest
+    // a2 gives the second smallest s~ of a subset of the rows, a bound as valid as pass 0's and tighter,
+    // and only the rows whose value is >= a2 - m (the margin of k_match_limits) are read and ranked: every
+    // row among the two nearest has a >= a2 - m, and its entry's value is at least its a. About half of
+    // the listed rows go (the margin m is a worst-case bound and wide against the spread of the best
+    // scores). Lists that overflowed are left to k_match_overflow as before.
+    float alim = -kInf;
+    if (refilter) {
+        float a1 = -kInf, a2 = -kInf;
+        int prev = 0x7fc00000;           // (a NaN: no product has these bits)
+        for (int sp = 0; sp * per < chunks; sp++) {
+            const size_t at = ((size_t)blockIdx.y * nsplit + sp) * nq_cap + i;
+            const int n = cnt_all[at];
+            if (n > kCandCap) continue;
+            const int2* __restrict__ list = cand_all + at * kCandCap;
+            for (int c = 0; c < n; c++) {
+                const int bits = list[c].y;
+                if (bits == prev) continue;     // the same lane's rows of one tile share their value
+                prev = bits;
+                const float a = __int_as_float(bits);
+                a2 = fmaxf(a2, fminf(a1, a));
+                a1 = fmaxf(a1, a);
+            }
+        }
+        const float dmax = __builtin_bit_cast(float, dnmax_all[blockIdx.y]);
+        const float m = kScreenRel * __builtin_sqrtf(qnv * dmax) + 3.0f * kScreenAbs * (qnv + dmax);
+        alim = a2 - m;                  // -inf while fewer than two rows are listed: every listed row is ranked
+    }
     for (int sp = 0; sp * per < chunks; sp++) {
         const size_t at = ((size_t)blockIdx.y * nsplit + sp) * nq_cap + i;
         const int n = cnt_all[at];
@@ -1441,9 +1493,11 @@ __global__ __launch_bounds__(128) void k_match_rank(PairTable tbl, int nq_cap, i
             deferred |= 1ull << sp;
             continue;
         }
-        const int* __restrict__ list = cand_all + at * kCandCap;
+        const int2* __restrict__ list = cand_all + at * kCandCap;
         for (int c = 0; c < n; c++) {
-            const int j = list[c];
+            const int2 e = list[c];
+            if (refilter && !(__int_as_float(e.y) >= alim)) continue;
+            const int j = e.x;
             const float* r = D + (size_t)j * ld;
             float acc = 0.0f;
 #pragma unroll
@@ -1713,7 +1767,7 @@ struct mif_matcher {
     unsigned int* dnmax = nullptr;  // [pairs]
     float* thr = nullptr;
     int* cand_cnt = nullptr;
-    int* cand = nullptr;            // [screen_slots][kCandCap]
+    int2* cand = nullptr;           // [screen_slots][kCandCap] (row, bits of the bf16 product it was kept for)
     size_t screen_slots = 0;
     // bf16 image of the database rows for the screening passes (k_match_pack_rows): [pairs][rows_pad][152]
     __bf16* dbf = nullptr;
@@ -1865,7 +1919,7 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
             if (screen) {
                 float* thr = m->thr + (size_t)base * m->max_q;                    // per (pair, split, query)
                 int* ccnt = m->cand_cnt + (size_t)base * m->max_q;
-                int* cand = m->cand + (size_t)base * m->max_q * kCandCap;
+                int2* cand = m->cand + (size_t)base * m->max_q * kCandCap;
                 static const bool screen_v1 = getenv("MIF_MATCH_SCREEN_V1") != nullptr;      // A/B switch
                 static const char* wide_env = getenv("MIF_MATCH_SCREEN_WIDE");               // A/B switch: 0 / 1
                 // 512 queries per work item where a pair has enough queries to fill such items and the
@@ -1931,11 +1985,15 @@ int match_batch(mif_matcher* m, const mif_match_pair* pairs, int npairs, int nq,
 #undef MIF_LAUNCH_SCREEN
 #undef MIF_LAUNCH_LIMITS
                 // (work[3]: the number of queued queries; zeroed with the other counters above)
+                // after a sampled first pass the lists are long: k_match_rank tightens the threshold first
+                static const bool no_refilter = getenv("MIF_MATCH_NO_REFILTER") != nullptr;  // A/B switch
+                const int refilter = (sample > 1 && !screen_v1 && !no_refilter) ? 1 : 0;
 #define MIF_LAUNCH_RANK(V)                                                                                       \
     do {                                                                                                         \
         hipLaunchKernelGGL(k_match_rank<V>, dim3((nq + 127) / 128, np), dim3(128), 0, st, tbl, nq, nd, dim, ld,  \
-                           (const float*)qn, (const float*)dn, nsplit, (const int*)ccnt, (const int*)cand, ps,  \
-                           pi, m->ovf + (size_t)base * m->max_q, m->work + 3);                                  \
+                           (const float*)qn, (const float*)dn, nsplit, (const int*)ccnt, (const int2*)cand, ps, \
+                           pi, m->ovf + (size_t)base * m->max_q, m->work + 3, (const unsigned int*)nmax,        \
+                           refilter);                                                                            \
         hipLaunchKernelGGL(k_match_overflow<V>, dim3(2 * m->blocks), dim3(256), 0, st, tbl, nq, nd, dim, ld,     \
                            (const float*)qn, (const float*)dn, nsplit,                                          \
                            (const OverflowEntry*)(m->ovf + (size_t)base * m->max_q),                            \
@@ -2127,7 +2185,7 @@ int mif_match_create_batched(int device, int max_query, int max_database, int ma
     // two values per (pair, split, query): the bound on the second smallest score, then the smallest score
     if ((e = hipMalloc(&m->thr, 2 * m->screen_slots * sizeof(float))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->cand_cnt, m->screen_slots * sizeof(int))) != hipSuccess) return fail(e);
-    if ((e = hipMalloc(&m->cand, m->screen_slots * kCandCap * sizeof(int))) != hipSuccess) return fail(e);
+    if ((e = hipMalloc(&m->cand, m->screen_slots * kCandCap * sizeof(int2))) != hipSuccess) return fail(e);
     if ((e = hipMalloc(&m->ovf, P * max_query * sizeof(OverflowEntry))) != hipSuccess) return fail(e);
     // the bf16 image of the database rows for the screening passes of large searches (kTurnsMinScores);
     // a matcher too small for those has none, and without it (out of memory) the passes stage the fp32
