@@ -164,6 +164,9 @@ def test_two_phase_enqueue_snapshot_and_stream_order():
     assert int(cnt.cpu()[0]) == n and n > 0
     assert np.array_equal(snap2.cpu().numpy()[:n], b.descriptors)
     assert np.all(snap2.cpu().numpy()[n:] == -1.0)          # only the frame's rows are written
+    # the snapshot moves 16-byte pieces: a misaligned buffer is refused before anything is enqueued
+    with pytest.raises(_lib.MifError):
+        two.snapshot_frame(B - 1, snap.data_ptr() + 4, cnt.data_ptr())
     # the feature phase needs a pending scale space
     with pytest.raises(_lib.MifError):
         two.enqueue_features(True)
