@@ -56,6 +56,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak
 # move (min_bytes_per_frame), so that it is a utilisation and stays below 1.
 ALG_UNFUSED_BYTES_PER_PX_OCTAVE = 104.0
 BLUR_TRAFFIC_FILE = os.path.join("profiles", "r03_blur_traffic.json")
+SURF_TRAFFIC_FILE = os.path.join("profiles", "r03_surf_traffic.json")
 SURF_INTEGRAL_BYTES_PER_PX = 16.0   # row scan r4 + w4, column scan r4 + w4 (the reference moves 32 with its transposes)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 DEMO_DIR = os.path.join(ROOT, "object_detection_amd", "cpp", "build")
@@ -805,6 +806,13 @@ def surf_batch_leg(args, oda, torch, device, local_rank, frames):
         done += 1
     cpu_fps = (done - 1) / (time.perf_counter() - t0) if done > 1 else 1.0 / cpu_s
     integ = SURF_INTEGRAL_BYTES_PER_PX * w * h * B / (stage[0] * 1e-3) / 1e9
+    # memory-side bytes of the two scan kernels from the counter passes (they scale with the frame count)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, SURF_TRAFFIC_FILE)) as fh:
+            traffic = json.load(fh)["integral_bytes_per_frame"] * B
+    except (OSError, KeyError, ValueError):
+        pass
     return {
         "workload": "SURF extraction of %d synthetic 1920x1080 BGR frames per step, resident in HBM "
                     "(mif_surf_enqueue_batch)" % B,
@@ -813,7 +821,8 @@ def surf_batch_leg(args, oda, torch, device, local_rank, frames):
         "stage_ms_per_batch": {k: float(v) for k, v in zip(ex.STAGES, stage)},
         "roofline": {"bound": "hbm", "kernel": "integral image (row scan + column scan)", "achieved": integ,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": integ / HBM_PEAK_GBS,
-                     "alg_bytes_per_px": SURF_INTEGRAL_BYTES_PER_PX, "traffic": None},
+                     "alg_bytes_per_px": SURF_INTEGRAL_BYTES_PER_PX, "traffic": traffic,
+                     "traffic_source": SURF_TRAFFIC_FILE + " (both scan kernels, per step)"},
         "verified": bool(ok),
         "cpu_baseline": {"value": cpu_fps, "unit": "frames/s", "cores": orc.lib().orc_get_threads(), "kind": "port",
                          "sample": "%d frames 1920x1080 BGR through the OpenMP restatement of the SURF pipeline "
