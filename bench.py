@@ -259,6 +259,7 @@ class Pipeline:
                 st = ctypes.c_void_p()
                 self._lib.check(self.lib.mif_stream_create_masked(dev_index, words, 8, ctypes.byref(st)))
                 self.masked.append(st.value)
+            self.created_streams = list(self.masked)
             if os.environ.get("BENCH_CU_SAME"):        # both handles on the first share: what a share can do alone
                 self.masked[1] = self.masked[0]
             self.h[0].set_stream(self.masked[0])
@@ -361,6 +362,17 @@ class Pipeline:
 
     def last(self):
         return (self.step_no - 1) % 2
+
+    def close(self):
+        """Detaches the handles from the streams this object created for them (mif_stream_create_masked)
+        and destroys those streams; the handles go back to their own streams, as the stream's lifetime
+        contract asks (a caller's stream must outlive its use by the handle or be detached first)."""
+        self.sync()
+        for h in self.h:                # (handle 1 runs on handle 0's stream in the default schedule)
+            h.set_stream(None)
+        for st in getattr(self, "created_streams", []):
+            self._lib.check(self.lib.mif_stream_destroy(self.dev_index, ctypes.c_void_p(st)))
+        self.created_streams = []
 
     def sync(self):
         self.flush()
@@ -1266,6 +1278,7 @@ def main():
     # stream is gone once the pipeline is.
     pipe.sync()
     host_state.clear()
+    pipe.close()
     del pipe, frames, step, timed
     torch.cuda.empty_cache()
 
