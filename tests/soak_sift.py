@@ -3,7 +3,7 @@
 channel counts and contents, single frames and small batches, with and without up_scale; every output must be
 bit-identical. Test infrastructure like the rest of this directory (it uses the checker), but not collected by
 pytest: it runs for as long as --seconds says; a failure prints the case.
-usage: python tests/soak_sift.py --seconds 120 [--seed 1]"""
+usage: python tests/soak_sift.py --seconds 120 [--seed 1] [--wide]"""
 import argparse
 import os
 import sys
@@ -27,12 +27,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--wide", action="store_true",
+                    help="images 1000 .. 4096 pixels wide and 40 .. 160 high: large column offsets at a small cost")
     args = ap.parse_args()
     import torch
     rng = np.random.RandomState(args.seed)
     t0, cases, keypoints, bad = time.time(), 0, 0, 0
     while time.time() - t0 < args.seconds:
         w, h = int(rng.randint(24, 420)), int(rng.randint(24, 320))
+        if args.wide:
+            w, h = int(rng.randint(1000, 4097)), int(rng.randint(40, 161))
         c = int(rng.choice([1, 3]))
         up = bool(rng.rand() < 0.15) and w * h < 60000
         batch = int(rng.choice([1, 1, 2, 3]))
