@@ -1,5 +1,5 @@
 # kernel trace of the 1 M x 1 M search (bench_match.py) with the in-tree library and, when given, with
-# gpurun_exp/<name>.so:  gpurun -- 'bash tools/rank_pmc.sh [name]'
+# gpurun_exp/<name>.so:  gpurun -- 'bash tools/trace_match.sh [name]'
 set -o pipefail
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
