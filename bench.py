@@ -57,6 +57,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak
 ALG_UNFUSED_BYTES_PER_PX_OCTAVE = 104.0
 BLUR_TRAFFIC_FILE = os.path.join("profiles", "r03_blur_traffic.json")
 SURF_TRAFFIC_FILE = os.path.join("profiles", "r03_surf_traffic.json")
+BLUR_4K_TRAFFIC_FILE = os.path.join("profiles", "r03_4k_blur_traffic.json")
 SURF_INTEGRAL_BYTES_PER_PX = 16.0   # row scan r4 + w4, column scan r4 + w4 (the reference moves 32 with its transposes)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 DEMO_DIR = os.path.join(ROOT, "object_detection_amd", "cpp", "build")
@@ -881,6 +882,13 @@ def sift_4k_leg(args, oda, torch, device, local_rank, frames_16):
         S.run(frames_16[done % len(frames_16)])
         done += 1
     cpu_fps = done / (time.perf_counter() - t0) if done else 1.0 / cpu_s
+    # memory-side bytes of the scale-space launches per step, from the counter passes (taken at batch 16)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, BLUR_4K_TRAFFIC_FILE)) as fh:
+            traffic = json.load(fh)["blur_bytes_per_frame"] * B
+    except (OSError, KeyError, ValueError):
+        pass
     return {
         "workload": "SIFT extraction (keypoints, orientations, descriptors) of %d synthetic 3840x2160 "
                     "single-channel frames per step, resident in HBM (%d distinct frames, seed 4321, repeated "
@@ -891,7 +899,8 @@ def sift_4k_leg(args, oda, torch, device, local_rank, frames_16):
                                "orient_desc": float(stage[:, 3].sum())},
         "roofline": {"bound": "hbm", "kernel": "k_blur_level / k_blur_pair", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "alg_bytes_per_frame": min_bytes_per_frame(opx, 1), "traffic": None},
+                     "alg_bytes_per_frame": min_bytes_per_frame(opx, 1), "traffic": traffic,
+                     "traffic_source": BLUR_4K_TRAFFIC_FILE + " (all scale-space launches of a step)"},
         "verified": bool(ok),
         "cpu_baseline": {"value": cpu_fps, "unit": "frames/s", "cores": orc.lib().orc_get_threads(), "kind": "port",
                          "sample": "%d frames 3840x2160 gray, extraction only, OpenMP restatement (oracle/)"

@@ -95,6 +95,14 @@ if has 4k; then
         python "$ROOT/bench.py" $PIPE --width 3840 --height 2160 --channels 1 --no-match --batch 64 --steps 5 --warmup 2 > "$OUT/bench_4k.json" 2> "$OUT/trace_4k.err"
     cp "$OUT"/trace_4k/t_kernel_stats.csv "$OUT/4k_kernel_stats.csv"
     python "$ROOT/tools/kstats.py" "$OUT/4k_kernel_stats.csv" 7 14
+    echo "[4k] FETCH_SIZE / WRITE_SIZE passes at batch 16"
+    K4="--width 3840 --height 2160 --channels 1 --no-match --batch 16 --steps 2 --warmup 1"
+    timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_4k_fetch" -o f -- \
+        python "$ROOT/bench.py" $PIPE $K4 > "$OUT/pmc_4k_fetch.log" 2>&1
+    timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_4k_write" -o w -- \
+        python "$ROOT/bench.py" $PIPE $K4 > "$OUT/pmc_4k_write.log" 2>&1
+    (cd "$ROOT" && python tools/pmc_traffic.py "$OUT"/pmc_4k_fetch/f_counter_collection.csv \
+        "$OUT"/pmc_4k_write/w_counter_collection.csv 16 "$OUT/4k_blur_traffic.json")
 fi
 
 if has micro; then
