@@ -45,7 +45,7 @@ constexpr int kBlurTile = 64;      // output tile edge of the blur kernel
 constexpr int kDescBlocks = 1024, kDescBlocksTotal = 65536;
 constexpr int kOriBlocks = 128, kOriBlocksTotal = 32768;
 #ifndef MIF_ORI_UNROLL
-#define MIF_ORI_UNROLL 2
+#define MIF_ORI_UNROLL 4
 #endif
 constexpr int kOriUnroll = MIF_ORI_UNROLL;   // window pixels a lane of k_orientation handles per turn
 
