@@ -42,7 +42,7 @@ constexpr int kBlurTile = 64;      // output tile edge of the blur kernel
 // mostly start blocks that exit at once; a block walks the list with the grid's stride instead.
 // Few blocks per frame balance badly (keypoints differ in cost): both values were measured.
 // Small batches get more blocks per frame, so that the launch still fills the GPU.
-constexpr int kDescBlocks = 1024, kDescBlocksTotal = 65536;
+constexpr int kDescBlocks = 1536, kDescBlocksTotal = 65536;
 constexpr int kOriBlocks = 128, kOriBlocksTotal = 32768;
 #ifndef MIF_ORI_UNROLL
 #define MIF_ORI_UNROLL 4
