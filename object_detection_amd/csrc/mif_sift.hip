@@ -902,7 +902,7 @@ constexpr int kDetCols = 62;        // output columns per wave
 constexpr float kContrPre = ((double)(float)K_CONTR_THR_1 <= K_CONTR_THR_1)
                                 ? (float)K_CONTR_THR_1
                                 : __builtin_nextafterf((float)K_CONTR_THR_1, 0.0f);
-constexpr int kDetRows = 32;        // rows per block
+constexpr int kDetRows = 18;        // rows per block (12 .. 24 measure alike, 32 and more 2.5 % slower)
 constexpr int kDetGroup = 3;        // rows loaded ahead
 
 template <bool GRAD>
