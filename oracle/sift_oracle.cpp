@@ -29,7 +29,7 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
-#include "../object_detection_amd/csrc/mif_math.h"
+#include "orc_math.h"
 
 namespace {
 

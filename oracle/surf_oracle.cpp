@@ -29,7 +29,7 @@
 #include <cfloat>
 #include <vector>
 #include <algorithm>
-#include "../object_detection_amd/csrc/mif_math.h"
+#include "orc_math.h"
 
 namespace {
 

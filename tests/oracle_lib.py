@@ -5,17 +5,18 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "build", "liboracle.so")
+# the same checker with the C library's exp / atan2 / sin / cos (oracle/orc_math.h)
+ORACLE_LIBM_SO = os.path.join(ROOT, "oracle", "build", "liboracle_libm.so")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(ORACLE_SO):
-            raise RuntimeError("oracle library missing: run `make -C oracle` (or __graft_entry__.build())")
-        L = C.CDLL(ORACLE_SO)
+def lib(path=ORACLE_SO):
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise RuntimeError("%s missing: run `make -C oracle` (or __graft_entry__.build())" % path)
+        L = C.CDLL(path)
         L.orc_sift_create.restype = C.c_void_p
         L.orc_sift_create.argtypes = [C.c_int, C.c_int, C.c_int]
         L.orc_sift_create_up.restype = C.c_void_p
@@ -64,8 +65,12 @@ def lib():
         L.orc_surf_points.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_set_threads.argtypes = [C.c_int]
         L.orc_get_threads.restype = C.c_int
-        _lib = L
-    return _lib
+        _libs[path] = L
+    return _libs[path]
+
+
+def lib_libm():
+    return lib(ORACLE_LIBM_SO)
 
 
 def math_array(op, a, b=None):
@@ -111,8 +116,8 @@ def _arr(ptr, n, dtype=np.float32):
 class SiftOracle:
     """One CPU run of the restated reference pipeline, with every intermediate image exposed."""
 
-    def __init__(self, width, height, channels=1, up_scale=False):
-        self.L = lib()
+    def __init__(self, width, height, channels=1, up_scale=False, library=None):
+        self.L = library or lib()
         self.h = self.L.orc_sift_create_up(width, height, channels, 1 if up_scale else 0)
         if not self.h:
             raise ValueError("bad image geometry")
@@ -199,8 +204,8 @@ def match_top2(q, db, dim=None, return_scores=False):
 class SurfOracle:
     """One CPU run of the restated reference SURF pipeline."""
 
-    def __init__(self, width, height):
-        self.L = lib()
+    def __init__(self, width, height, library=None):
+        self.L = library or lib()
         self.h = self.L.orc_surf_create(width, height)
         if not self.h:
             raise ValueError("bad image geometry")
