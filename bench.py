@@ -58,7 +58,10 @@ ALG_UNFUSED_BYTES_PER_PX_OCTAVE = 104.0
 BLUR_TRAFFIC_FILE = os.path.join("profiles", "r03_blur_traffic.json")
 SURF_TRAFFIC_FILE = os.path.join("profiles", "r03_surf_traffic.json")
 BLUR_4K_TRAFFIC_FILE = os.path.join("profiles", "r03_4k_blur_traffic.json")
-SURF_INTEGRAL_BYTES_PER_PX = 16.0   # row scan r4 + w4, column scan r4 + w4 (the reference moves 32 with its transposes)
+# integral image of a BGR frame: 3 bytes read, 4 written (both passes in one launch); a launch per pass moves
+# r3 + w4 + r4 + w4 = 15, the reference with its transposes about 32
+SURF_INTEGRAL_BYTES_PER_PX = 7.0
+SURF_INTEGRAL_TWO_PASS_BYTES_PER_PX = 15.0
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 DEMO_DIR = os.path.join(ROOT, "object_detection_amd", "cpp", "build")
 
@@ -779,7 +782,7 @@ def check_pair_leg(kind, report, budget_s=4.0):
 
 def surf_batch_leg(args, oda, torch, device, local_rank, frames):
     """BASELINE.json configs[1] at throughput: a batch of 1080p BGR frames resident in HBM through
-    mif_surf_enqueue_batch; frames/s, the integral image's achieved bandwidth against 16 B/px, frame 1
+    mif_surf_enqueue_batch; frames/s, the integral image's achieved bandwidth against 7 B/px (3 read, 4 written), frame 1
     compared with the CPU checker, and the checker's own rate beside it."""
     import oracle_lib as orc
     B, w, h = args.config_batch, 1920, 1080
@@ -832,10 +835,13 @@ def surf_batch_leg(args, oda, torch, device, local_rank, frames):
         "value": B / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "steps": args.config_steps,
         "points_frame1": int(n),
         "stage_ms_per_batch": {k: float(v) for k, v in zip(ex.STAGES, stage)},
-        "roofline": {"bound": "hbm", "kernel": "integral image (row scan + column scan)", "achieved": integ,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": integ / HBM_PEAK_GBS,
-                     "alg_bytes_per_px": SURF_INTEGRAL_BYTES_PER_PX, "traffic": traffic,
-                     "traffic_source": SURF_TRAFFIC_FILE + " (both scan kernels, per step)"},
+        "roofline": {"bound": "hbm", "kernel": "integral image (k_integral_fused: row scan and column scan in one "
+                                               "launch; the stage's time includes clearing the response pools)",
+                     "achieved": integ, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": integ / HBM_PEAK_GBS,
+                     "alg_bytes_per_px": SURF_INTEGRAL_BYTES_PER_PX,
+                     "achieved_two_pass_bytes": integ * SURF_INTEGRAL_TWO_PASS_BYTES_PER_PX / SURF_INTEGRAL_BYTES_PER_PX,
+                     "traffic": traffic,
+                     "traffic_source": SURF_TRAFFIC_FILE + " (the integral-image launch, per step)"},
         "verified": bool(ok),
         "cpu_baseline": {"value": cpu_fps, "unit": "frames/s", "cores": orc.lib().orc_get_threads(), "kind": "port",
                          "sample": "%d frames 1920x1080 BGR through the OpenMP restatement of the SURF pipeline "

@@ -81,9 +81,8 @@ __constant__ unsigned char c_orient_slot[109];
 // `last` is the index of the frame's last pixel: a BGR pixel is fetched as one (unaligned) 32-bit word
 // that starts at its B byte, or one byte earlier for the frame's last pixel so that the word ends with
 // the frame.
-__device__ __forceinline__ float gray_of(const uint8_t* __restrict__ px, int i, int channels, int last)
+__device__ __forceinline__ uint32_t gray_fetch(const uint8_t* __restrict__ px, int i, int channels, int last)
 {
-    int g;
     if (channels == 3) {
         uint32_t v;
         if (last >= 1) {
@@ -93,12 +92,26 @@ __device__ __forceinline__ float gray_of(const uint8_t* __restrict__ px, int i, 
         } else {                                     // a frame of one pixel holds three bytes only
             v = px[0] | (px[1] << 8) | (px[2] << 16);
         }
+        return v;
+    }
+    return px[i];
+}
+
+__device__ __forceinline__ float gray_value(uint32_t v, int channels)
+{
+    int g;
+    if (channels == 3) {
         const int b = v & 255u, gg = (v >> 8) & 255u, r = (v >> 16) & 255u;
         g = (b * 1868 + gg * 9617 + r * 4899 + (1 << 13)) >> 14;
     } else {
-        g = px[i];
+        g = (int)v;
     }
     return (float)((double)g * (1.0 / 255.0));
+}
+
+__device__ __forceinline__ float gray_of(const uint8_t* __restrict__ px, int i, int channels, int last)
+{
+    return gray_value(gray_fetch(px, i, channels, last), channels);
 }
 
 // Inclusive scan over the 64 lanes of a wave with offsets 1, 2, ..., 32: the
@@ -225,6 +238,225 @@ __global__ __launch_bounds__(64) void k_scan_cols_serial(float* __restrict__ img
         for (int i = 0; i < 64; i++)
             if (y0 + i < h) img[(size_t)(y0 + i) * w + x] = a[i] + prev;
         prev += a[63];
+    }
+}
+
+// Both passes in one launch: 3 (or 1) bytes read and 4 written per pixel instead of 3 + 4 + 4 + 4.
+//
+// A workgroup owns a band of 64 image rows of one frame, i.e. one row block of the column pass, and walks
+// it from left to right a tile of 64 x 64 pixels, i.e. one column block of the row pass, at a time. Its
+// four waves form a pipeline over the tiles, a barrier apart:
+//   waves 0, 1  load tile s (a lane per column, coalesced), convert to gray, write it to LDS
+//   wave 2      row pass of tile s - 1 with a lane per ROW: the tile's row in 64 registers, the tree in
+//               registers (descending index, so every step reads values of the previous step), plus the
+//               running total of the row's blocks to the left, which is one register of the lane; the
+//               result goes back to LDS in place
+//   wave 3      column pass of tile s - 2 with a lane per COLUMN, the same tree over the 64 rows; the total
+//               of the row blocks above comes from the band above (below), is added, and the rows go to
+//               memory as coalesced 256-byte segments
+// so no step of either tree moves data between lanes. Three LDS tiles rotate through the three roles
+// (pitch 65 floats: both the row-wise and the column-wise accesses are free of bank conflicts).
+//
+// The running total over the row blocks, prev_k = (((0 + t_0) + t_1) + ...) + t_(k-1), is handed down from
+// band to band: wave 3 of band k publishes prev_(k+1) = prev_k + t_k for its 64 columns as soon as it has
+// prev_k, as 64-bit words {value, launch number} written and polled with relaxed device-scope atomics
+// (one word carries both, so no fence is needed; a word of an earlier launch has another number). The
+// bands of a frame run one tile behind each other. Bands take their number from a ticket counter, frame
+// major and top to bottom, so the band a workgroup waits for has always started before it, and the top
+// band waits for nobody: every wait ends. The wait is bounded all the same; a band that gives up raises
+// `fault` (k_scan_counts then reports the frame as failed) and goes on with zeros.
+constexpr int kFuPitch = 65;
+constexpr int kFuSpin = 1 << 21;
+constexpr int kFusedMinBands = 192;     // bands of a batch from which the one-launch form is used (measured:
+                                        // 1080p, 8 frames = 136 bands 3 % slower than two launches, 16 frames = 272 bands 3.5 % faster)
+
+template <int CH, bool A4>
+__global__ __launch_bounds__(256) void k_integral_fused(const uint8_t* __restrict__ px, float* __restrict__ out, int w,
+                                                        int h, int nbands, int nitems,
+                                                        unsigned long long* __restrict__ carry, int wpad,
+                                                        unsigned int epoch, unsigned int* __restrict__ ticket,
+                                                        int* __restrict__ fault)
+{
+    __shared__ float s_t[3][64 * kFuPitch];
+    __shared__ int s_item;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    if (tid == 0) s_item = (int)atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int item = s_item;
+    if (item >= nitems) return;                              // uniform over the workgroup
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int f = item / nbands, band = item - f * nbands;
+    const int y0 = band * 64;
+    px += (size_t)f * w * h * CH;
+    out += (size_t)f * w * h;
+    unsigned long long* carry_out = carry + ((size_t)f * nbands + band) * wpad;
+    const unsigned long long* carry_in = carry_out - wpad;   // read for band > 0 only
+    const int ncb = (w + 63) / 64;
+    const int last = w * h - 1;                              // at least 1 (the host sends smaller frames elsewhere)
+    const bool whole = y0 + 64 <= h;
+    // Every role has a loop of its own (the registers of one role are then not live in the others), with
+    // the same number of barriers: ncb + 2. A step's barrier waits for the wave's LDS operations only: a
+    // __syncthreads() would also wait for the loads of the next tile and for the stores of the finished
+    // one, a round trip to memory per step.
+    auto step_barrier = [] {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    if (wave < 2 && A4) {
+        // Widths that are multiples of four: a lane owns four adjacent pixels of one row, 12 bytes of a BGR
+        // frame (4 of a gray one) that start on a 4-byte boundary, and fetches them with one load; a wave's
+        // load covers 4 rows x 64 columns. The raw words of the next tile are loaded a step ahead.
+        constexpr int NW = CH == 3 ? 3 : 1;
+        const int rr = lane >> 4, g = lane & 15;
+        typedef uint32_t RawWords __attribute__((ext_vector_type(CH == 3 ? 3 : 1)));      // one load, one register tuple
+        RawWords raw[8];
+        auto fetch_tile = [&](int s) {
+            // positions outside the image read the nearest group inside (and become zeros when they are
+            // converted): no branch, all loads in flight together
+            const int xc = min(s * 64 + 4 * g, w - 4);
+#pragma unroll
+            for (int it = 0; it < 8; it++) {
+                const int yc = min(y0 + 32 * wave + 4 * it + rr, h - 1);
+                raw[it] = *(const RawWords*)(px + ((size_t)yc * w + xc) * CH);
+            }
+        };
+        fetch_tile(0);
+        for (int s = 0; s < ncb + 2; s++) {
+            if (s < ncb) {
+                float* t = s_t[s % 3];
+                const bool xin = s * 64 + 4 * g < w;
+#pragma unroll
+                for (int it = 0; it < 8; it++) {
+                    const int row = 32 * wave + 4 * it + rr;
+                    const bool in = xin && y0 + row < h;
+                    uint32_t p[4];
+                    if (CH == 3) {
+                        const uint32_t w0 = raw[it][0], w1 = raw[it][NW > 1 ? 1 : 0], w2 = raw[it][NW > 2 ? 2 : 0];
+                        p[0] = w0 & 0xffffffu;
+                        p[1] = (w0 >> 24) | ((w1 & 0xffffu) << 8);
+                        p[2] = (w1 >> 16) | ((w2 & 0xffu) << 16);
+                        p[3] = w2 >> 8;
+                    } else {
+                        const uint32_t w0 = raw[it][0];
+                        p[0] = w0 & 255u; p[1] = (w0 >> 8) & 255u; p[2] = (w0 >> 16) & 255u; p[3] = w0 >> 24;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) t[row * kFuPitch + 4 * g + j] = in ? gray_value(p[j], CH) : 0.0f;
+                }
+                if (s + 1 < ncb) fetch_tile(s + 1);
+            }
+            step_barrier();
+        }
+    } else if (wave < 2) {
+        // the raw pixels of the next tile are loaded a step ahead
+        uint32_t raw[32];
+        auto fetch_tile = [&](int s) {
+            // positions outside the image read the nearest pixel inside (and become zeros when they are
+            // converted): the loads then need no branch and are all in flight together
+            const int xc = min(s * 64 + lane, w - 1);
+            // (row addresses are scalars formed here, step by step: see the stores of wave 3)
+            size_t pitch = (size_t)w * CH;
+            asm volatile("" : "+s"(pitch));
+            const int ya = y0 + 32 * wave;
+            const uint8_t* row = px + (size_t)min(ya, h - 1) * w * CH;
+#pragma unroll
+            for (int r = 0; r < 32; r++) {
+                const int yc = min(ya + r, h - 1);
+                if (CH == 3) {  // one (unaligned) word from the pixel's B byte, one byte earlier for the last pixel
+                    const int back = (yc * w + xc < last) ? 0 : 1;
+                    uint32_t v;
+                    __builtin_memcpy(&v, row + (3 * xc - back), 4);
+                    raw[r] = v >> (8 * back);
+                } else {
+                    raw[r] = row[xc];
+                }
+                if (ya + r + 1 <= h - 1) row += pitch;
+            }
+        };
+        fetch_tile(0);
+        for (int s = 0; s < ncb + 2; s++) {
+            if (s < ncb) {
+                float* t = s_t[s % 3];
+                const int x = s * 64 + lane;
+#pragma unroll
+                for (int r = 0; r < 32; r++) {
+                    const int y = y0 + 32 * wave + r;
+                    t[(32 * wave + r) * kFuPitch + lane] = (x < w && y < h) ? gray_value(raw[r], CH) : 0.0f;
+                }
+                if (s + 1 < ncb) fetch_tile(s + 1);
+            }
+            step_barrier();
+        }
+    } else if (wave == 2) {
+        float prev_row = 0.0f;                               // total of this lane's row left of the tile
+        for (int s = 0; s < ncb + 2; s++) {
+            if (s >= 1 && s - 1 < ncb) {
+                float* t = s_t[(s - 1) % 3] + lane * kFuPitch;
+                float a[64];
+#pragma unroll
+                for (int j = 0; j < 64; j++) a[j] = t[j];
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+                    for (int j = 63; j >= d; j--) a[j] = a[j] + a[j - d];
+                }
+#pragma unroll
+                for (int j = 0; j < 64; j++) t[j] = a[j] + prev_row;
+                prev_row += a[63];
+            }
+            step_barrier();
+        }
+    } else {
+        for (int s = 0; s < ncb + 2; s++) {
+            if (s >= 2) {
+                const float* t = s_t[(s - 2) % 3];
+                const int x = (s - 2) * 64 + lane;
+                // the word of the band above is asked for before the tree and looked at after it
+                unsigned long long v = 0ull;
+                const bool chained = band > 0;
+                if (chained) v = __hip_atomic_load(&carry_in[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float a[64];
+#pragma unroll
+                for (int i = 0; i < 64; i++) a[i] = t[i * kFuPitch + lane];
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+                    for (int i = 63; i >= d; i--) a[i] = a[i] + a[i - d];
+                }
+                float prev = 0.0f;
+                if (chained) {
+                    int tries = 0;
+                    while ((unsigned int)(v >> 32) != epoch) {
+                        if (++tries >= kFuSpin) { atomicExch(fault, 1); v = 0ull; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        v = __hip_atomic_load(&carry_in[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    prev = __uint_as_float((unsigned int)v);
+                }
+                if (band + 1 < nbands)
+                    __hip_atomic_store(&carry_out[x], ((unsigned long long)epoch << 32) | __float_as_uint(prev + a[63]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (x < w) {
+                    // a scalar row address that moves down a row per store, plus the lane's column (the row
+                    // pitch is hidden from the compiler, which would otherwise keep 64 row addresses in
+                    // scalar registers across the loop and spill them)
+                    size_t pitch = (size_t)w;
+                    asm volatile("" : "+s"(pitch));
+                    float* o = out + (size_t)y0 * w + (s - 2) * 64;
+                    if (whole) {
+#pragma unroll
+                        for (int i = 0; i < 64; i++, o += pitch) o[lane] = a[i] + prev;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 64; i++, o += pitch)
+                            if (y0 + i < h) o[lane] = a[i] + prev;
+                    }
+                }
+            }
+            step_barrier();
+        }
     }
 }
 
@@ -554,7 +786,8 @@ __global__ __launch_bounds__(64) void k_nms_mark(LayerTable tab, NmsTable nms, c
 
 // Exclusive scan of the row totals, point count cut at maxIpts. One block per frame.
 __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ rowcnt, int* __restrict__ rowoff,
-                                                      int rows, int max_ipts, int* __restrict__ counts)
+                                                      int rows, int max_ipts, int* __restrict__ counts,
+                                                      const int* __restrict__ fault)
 {
     __shared__ int s_part[1024];
     const int tid = threadIdx.x;
@@ -579,8 +812,10 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ ro
         run += rowcnt[i];
     }
     if (tid == 1023) {
-        counts[0] = min(s_part[1023], max_ipts);
-        counts[1] = s_part[1023];
+        // a batch whose integral images are not to be trusted (k_integral_fused) has no points: raw total -2
+        const bool bad = *fault != 0;
+        counts[0] = bad ? 0 : min(s_part[1023], max_ipts);
+        counts[1] = bad ? -2 : s_part[1023];
     }
 }
 
@@ -992,6 +1227,10 @@ struct mif_surf {
     int* laplacians = nullptr;
     unsigned long long* mask = nullptr;
     int* rowcnt = nullptr;
+    unsigned int* ticket = nullptr;      // k_integral_fused: band numbers; cleared with the rest
+    int* fault = nullptr;                // k_integral_fused: a band gave up waiting
+    unsigned long long* carry = nullptr; // k_integral_fused: [batch][bands][columns padded to 64] {total, launch}
+    unsigned int epoch = 0;              // launch number of the last fused launch
     mif_ipoint* packed = nullptr;        // the points as mif_ipoint records, for a single download
     int* rowoff = nullptr;
     int* counts = nullptr;               // {points (cut at 8000), raw total}
@@ -1008,7 +1247,7 @@ namespace {
 void surf_free(mif_surf* s)
 {
     (void)hipFree(s->d_pixels); (void)hipFree(s->integral); (void)hipFree(s->cleared); (void)hipFree(s->rowoff);
-    (void)hipFree(s->packed);
+    (void)hipFree(s->packed); (void)hipFree(s->carry);
     (void)hipFree(s->counts); (void)hipFree(s->pos); (void)hipFree(s->scale); (void)hipFree(s->lap);
     (void)hipFree(s->orient); (void)hipFree(s->desc);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
@@ -1061,13 +1300,18 @@ int surf_create_impl(mif_surf* s)
         const size_t b_resp = up(B * s->pool * sizeof(float)), b_lap = up(B * s->pool * sizeof(int));
         const size_t b_mask = up(B * (size_t)std::max(rows, 1) * s->nms.words * sizeof(unsigned long long));
         const size_t b_cnt = up(B * (size_t)std::max(rows, 1) * sizeof(int));
-        s->cleared_bytes = b_resp + b_lap + b_mask + b_cnt;
+        s->cleared_bytes = b_resp + b_lap + b_mask + b_cnt + 256;
         MIF_HIP(hipMalloc(&s->cleared, s->cleared_bytes));
         char* base = (char*)s->cleared;
         s->responses = (float*)base;
         s->laplacians = (int*)(base + b_resp);
         s->mask = (unsigned long long*)(base + b_resp + b_lap);
         s->rowcnt = (int*)(base + b_resp + b_lap + b_mask);
+        s->ticket = (unsigned int*)(base + b_resp + b_lap + b_mask + b_cnt);
+        s->fault = (int*)(s->ticket + 1);
+        const size_t carry_bytes = B * (size_t)((s->H + 63) / 64) * (size_t)((s->W + 63) / 64 * 64) * sizeof(unsigned long long);
+        MIF_HIP(hipMalloc(&s->carry, carry_bytes));
+        MIF_HIP(hipMemset(s->carry, 0, carry_bytes));
     }
     MIF_HIP(hipMalloc(&s->packed, B * kMaxIpts * sizeof(mif_ipoint)));
     MIF_HIP(hipMalloc(&s->rowoff, B * (size_t)std::max(rows, 1) * sizeof(int)));
@@ -1110,12 +1354,32 @@ int surf_enqueue(mif_surf* s, const void* d_pixels, int nf)
     // positions no work item writes read as zero, as in freshly allocated buffers
     // (one memset: response and laplacian pools, acceptance mask, row counts)
     MIF_HIP(hipMemsetAsync(s->cleared, 0, s->cleared_bytes, st));
-    hipLaunchKernelGGL(k_scan_rows, dim3((h + 3) / 4, nf), dim3(256), 0, st, (const uint8_t*)d_pixels, s->integral, w, h,
-                       s->C);
-    if ((h + 63) / 64 <= kColMaxBlocks)
-        hipLaunchKernelGGL(k_scan_cols, dim3((w + 63) / 64, nf), dim3(64 * kColWaves), 0, st, s->integral, w, h);
-    else
-        hipLaunchKernelGGL(k_scan_cols_serial, dim3((w + 63) / 64, nf), dim3(64), 0, st, s->integral, w, h);
+    // both passes of the integral image in one launch for batches (a single frame has too few bands to fill
+    // the device: the two-pass form is faster there); MIF_SURF_INTEGRAL=fused / twopass forces a form
+    static const char* form_env = getenv("MIF_SURF_INTEGRAL");
+    const int nbands = (h + 63) / 64;
+    const bool fused = w * h >= 2 && (form_env ? strcmp(form_env, "fused") == 0 : nbands * nf >= kFusedMinBands);
+    if (fused) {
+        if (++s->epoch == 0) {                              // the launch numbers have wrapped: forget the old words
+            MIF_HIP(hipMemsetAsync(s->carry, 0, (size_t)s->batch * nbands * ((w + 63) / 64 * 64) * sizeof(unsigned long long), st));
+            s->epoch = 1;
+        }
+        // (four pixels per load where every row of every frame starts on a 4-byte boundary)
+        const bool a4 = w % 4 == 0 && (uintptr_t)d_pixels % 4 == 0;
+#define MIF_LAUNCH_FUSED(CH, A4)                                                                                          \
+    hipLaunchKernelGGL((k_integral_fused<CH, A4>), dim3(nbands * nf), dim3(256), 0, st, (const uint8_t*)d_pixels,          \
+                       s->integral, w, h, nbands, nbands * nf, s->carry, (w + 63) / 64 * 64, s->epoch, s->ticket, s->fault)
+        if (s->C == 3) { if (a4) MIF_LAUNCH_FUSED(3, true); else MIF_LAUNCH_FUSED(3, false); }
+        else { if (a4) MIF_LAUNCH_FUSED(1, true); else MIF_LAUNCH_FUSED(1, false); }
+#undef MIF_LAUNCH_FUSED
+    } else {
+        hipLaunchKernelGGL(k_scan_rows, dim3((h + 3) / 4, nf), dim3(256), 0, st, (const uint8_t*)d_pixels, s->integral, w, h,
+                           s->C);
+        if ((h + 63) / 64 <= kColMaxBlocks)
+            hipLaunchKernelGGL(k_scan_cols, dim3((w + 63) / 64, nf), dim3(64 * kColWaves), 0, st, s->integral, w, h);
+        else
+            hipLaunchKernelGGL(k_scan_cols_serial, dim3((w + 63) / 64, nf), dim3(64), 0, st, s->integral, w, h);
+    }
     if (tm) MIF_HIP(hipEventRecord(s->ev_stage[1], st));
     // the first octave's four layers from a window staged in LDS where they share one output grid (they do
     // for every image the reference's layer table is built for), the rest straight from memory
@@ -1135,7 +1399,7 @@ int surf_enqueue(mif_surf* s, const void* d_pixels, int nf)
     hipLaunchKernelGGL(k_nms_mark, dim3(s->nms.words, s->nms_max_h, kNms * nf), dim3(64), 0, st, s->tab, s->nms,
                        (const float*)s->responses, (const int*)s->laplacians, kThres, s->mask, s->rowcnt, s->pool);
     hipLaunchKernelGGL(k_scan_counts, dim3(nf), dim3(1024), 0, st, (const int*)s->rowcnt, s->rowoff, s->nms.rows,
-                       kMaxIpts, s->counts);
+                       kMaxIpts, s->counts, (const int*)s->fault);
     if (s->nms.rows > 0)
         hipLaunchKernelGGL(k_nms_emit, dim3((s->nms.rows + 3) / 4, nf), dim3(256), 0, st, s->tab, s->nms,
                            (const float*)s->responses, (const int*)s->laplacians,
@@ -1241,6 +1505,10 @@ int mif_surf_copy_points(mif_surf* s, int frame, mif_ipoint* points, int capacit
                            s->stream));
     MIF_HIP(hipStreamSynchronize(s->stream));
     const int n = s->h_counts[2 * frame];
+    if (s->h_counts[2 * frame + 1] == -2) {
+        mif::set_error("mif_surf_copy_points: the integral image pass of this batch did not complete");
+        return MIF_ERR_HIP;
+    }
     if (raw_count) *raw_count = s->h_counts[2 * frame + 1];
     if (n > capacity) {
         mif::set_error("mif_surf_copy_points: %d interest points do not fit capacity %d", n, capacity);
@@ -1292,6 +1560,10 @@ int mif_surf_run(mif_surf* s, const uint8_t* pixels, mif_ipoint* points, int cap
     MIF_HIP(hipStreamSynchronize(s->stream));
     if (elapsed_ms) MIF_HIP(hipEventElapsedTime(elapsed_ms, s->ev0, s->ev1));
     const int n = s->h_counts[0];
+    if (s->h_counts[1] == -2) {
+        mif::set_error("mif_surf_run: the integral image pass did not complete");
+        return MIF_ERR_HIP;
+    }
     if (raw_count) *raw_count = s->h_counts[1];
     if (n > capacity) {
         mif::set_error("mif_surf_run: %d interest points do not fit capacity %d", n, capacity);

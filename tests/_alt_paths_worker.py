@@ -43,6 +43,7 @@ def main(out):
     pts, raw = sx.run(frames[0])
     res["surf_points"] = pts.view(np.uint8)
     res["surf_raw"] = np.int32(raw)
+    res["surf_integral"] = sx.integral()
     for layer in (0, 3, 7):
         r, l = sx.layer(layer)
         res["surf_resp%d" % layer], res["surf_lap%d" % layer] = r, l

@@ -57,6 +57,18 @@ def test_staging_and_surf_switches(tmp_path):
         assert ref[k].shape == alt[k].shape and ref[k].tobytes() == alt[k].tobytes(), k
 
 
+@pytest.mark.parametrize("form", ["fused", "twopass"])
+def test_surf_integral_image_forms(tmp_path, form):
+    """MIF_SURF_INTEGRAL forces one form of the integral image at any size: both passes in one launch with
+    the bands of a frame handing their column totals down (what batches use by themselves), or a launch
+    per pass (what single frames use). Integral image, response layers and points: the default's bits."""
+    ref = _run(tmp_path, "default", {})
+    alt = _run(tmp_path, form, {"MIF_SURF_INTEGRAL": form})
+    for k in ref.files:
+        if k.startswith("surf_"):
+            assert ref[k].shape == alt[k].shape and ref[k].tobytes() == alt[k].tobytes(), k
+
+
 @pytest.mark.parametrize("mask", ["0", "7"])
 def test_scale_space_levels_singly_or_in_pairs(tmp_path, mask):
     """MIF_BLUR_PAIRS selects which levels of an octave are built two per launch (default: levels 0 and 1

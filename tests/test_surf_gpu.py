@@ -126,6 +126,35 @@ def test_surf_batches_equal_single_frames(channels):
     assert lib.mif_surf_batch(ex._h) == 4
 
 
+@pytest.mark.parametrize("w,h,channels", [(200, 130, 3), (203, 129, 3), (64, 193, 1), (131, 140, 1)])
+def test_surf_batch_with_both_passes_of_the_integral_image_in_one_launch(w, h, channels):
+    """Batches of 192 bands of 64 rows and more take the integral image's one-launch form (bands of a frame
+    hand their column totals down through memory): 64 and 70 frames of 3 / 4 bands, widths that are and are
+    not multiples of four (four pixels per load, or one), then a smaller batch on the same handle (below
+    the limit: a launch per pass) and the large one again. Integral image and points of probed frames equal
+    the checker's."""
+    import torch
+    B = 70
+    frames = np.stack([blob_image(w, h, seed=300 + i, channels=channels, shift=(i % 7, i % 5)) for i in range(B)])
+    frames[5] = 0
+    frames[6] = 255
+    dev = torch.device("cuda:0")
+    px = torch.from_numpy(frames).to(dev)
+    ex = oda.SurfExtractor(w, h, channels, batch=B)
+    S = orc.SurfOracle(w, h)
+    for nf in (64, 70, 9, 70):
+        assert ((h + 63) // 64) * nf >= 192 or nf == 9
+        ex.enqueue_batch(px.data_ptr(), nf)
+        for f in sorted({0, 5, 6, nf // 2, nf - 1}):
+            n = S.run(frames[f])
+            assert np.array_equal(ex.integral(f).view(np.uint32), S.integral().view(np.uint32)), (nf, f)
+            pts, raw = ex.copy_points(f)
+            assert len(pts) == n and raw == S.raw_count(), (nf, f)
+            if n:
+                assert np.array_equal(pts["descriptor"].view(np.uint32), S.points()[:, 6:].view(np.uint32)), (nf, f)
+    ex.close()
+
+
 def test_surf_tall_image_column_scan():
     """More rows than the tiled column scan's table of block totals holds (8192): the one-lane-per-column
     form takes over; the integral image still equals the checker's."""

@@ -83,6 +83,8 @@ if has surf; then
         --output-format csv -d "$OUT/pmc_surf_mem" -o q -- $SURF > "$OUT/pmc_surf_mem.log" 2>&1
     timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_surf_fetch" -o q -- $SURF > "$OUT/pmc_surf_fetch.log" 2>&1
     timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_surf_write" -o q -- $SURF > "$OUT/pmc_surf_write.log" 2>&1
+    (cd "$ROOT/tools" && python surf_traffic.py "$OUT"/pmc_surf_fetch/q_counter_collection.csv \
+        "$OUT"/pmc_surf_write/q_counter_collection.csv 64 "$OUT/surf_traffic.json")
     for c in sq mem fetch write; do
         python "$ROOT/tools/pmc_summary.py" "$OUT"/pmc_surf_$c/q_counter_collection.csv | grep -v "rocclr\|at::native"
     done > "$OUT/surf_counters_batch64.txt"
