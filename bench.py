@@ -58,10 +58,11 @@ ALG_UNFUSED_BYTES_PER_PX_OCTAVE = 104.0
 BLUR_TRAFFIC_FILE = os.path.join("profiles", "r03_blur_traffic.json")
 SURF_TRAFFIC_FILE = os.path.join("profiles", "r03_surf_traffic.json")
 BLUR_4K_TRAFFIC_FILE = os.path.join("profiles", "r03_4k_blur_traffic.json")
-# integral image of a BGR frame: 3 bytes read, 4 written (both passes in one launch); a launch per pass moves
-# r3 + w4 + r4 + w4 = 15, the reference with its transposes about 32
+# integral image of a BGR frame: 3 bytes read, 4 written (both passes in one launch). The unit of a scan per
+# pass, r4 + w4 twice = 16 B/px, is kept beside it (a launch per pass moves 15, the reference with its
+# transposes about 32).
 SURF_INTEGRAL_BYTES_PER_PX = 7.0
-SURF_INTEGRAL_TWO_PASS_BYTES_PER_PX = 15.0
+SURF_INTEGRAL_UNFUSED_BYTES_PER_PX = 16.0
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 DEMO_DIR = os.path.join(ROOT, "object_detection_amd", "cpp", "build")
 
@@ -839,7 +840,8 @@ def surf_batch_leg(args, oda, torch, device, local_rank, frames):
                                                "launch; the stage's time includes clearing the response pools)",
                      "achieved": integ, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": integ / HBM_PEAK_GBS,
                      "alg_bytes_per_px": SURF_INTEGRAL_BYTES_PER_PX,
-                     "achieved_two_pass_bytes": integ * SURF_INTEGRAL_TWO_PASS_BYTES_PER_PX / SURF_INTEGRAL_BYTES_PER_PX,
+                     "alg_unfused_bytes_per_px": SURF_INTEGRAL_UNFUSED_BYTES_PER_PX,
+                     "achieved_alg_unfused": integ * SURF_INTEGRAL_UNFUSED_BYTES_PER_PX / SURF_INTEGRAL_BYTES_PER_PX,
                      "traffic": traffic,
                      "traffic_source": SURF_TRAFFIC_FILE + " (the integral-image launch, per step)"},
         "verified": bool(ok),
