@@ -1003,27 +1003,35 @@ __global__ __launch_bounds__(128) void k_orientation(const float* __restrict__ i
         const float ry = gauss * hy;
         s_rx[slot] = rx;
         s_ry[slot] = ry;
-        s_rz[slot] = get_angle(rx, ry);
+        const float ang = get_angle(rx, ry);
+        s_rz[slot] = (ang > 0 && ang < 2 * kPiF) ? ang : __builtin_nanf("");     // see the window test below
     }
     __syncthreads();
+    // The 42 windows. 0..34 lie inside [0, 2 pi): ang1 < ang && ang < ang2. 35..41 wrap around:
+    // (ang > 0 && ang < ang2) || (ang > ang1 && ang < 2 pi). The angles are 0 .. 2 pi or NaN, and the ends
+    // of that range (like NaN) lie in no window of either kind, so they are stored as NaN and the wrapped
+    // test becomes ang < ang2 || ang > ang1: both kinds share the two comparisons of a sample and differ
+    // in how the lane masks combine.
     if (tid < 42) {
         const float ang1 = 0.15f * (float)tid;
         const float ang2 = (ang1 + (kPiF / 3.0f) > 2 * kPiF ? ang1 - (5.0f * kPiF / 3.0f) : ang1 + (kPiF / 3.0f));
+        // A sample outside the window contributes s_rx[k] * 0.0f = +-0 in the reference, which leaves the sum
+        // as it is (the sum starts at +0 and x + -x is +0, so it never is -0): what is added here is s_rx[k]
+        // or 0.0f, chosen by the lane mask that the two comparisons and the kind of window give (scalar
+        // operations on the comparisons' masks, then one select per component).
+        const uint64_t wrapped = __builtin_amdgcn_ballot_w64(tid > 34);
         float sx = 0.f, sy = 0.f;
-        if (tid <= 34) {
-            for (int k = 0; k < 109; ++k) {
-                const float ang = s_rz[k];
-                const int check = ang1 < ang && ang < ang2;
-                sx += s_rx[k] * (float)check;
-                sy += s_ry[k] * (float)check;
-            }
-        } else {
-            for (int k = 0; k < 109; ++k) {
-                const float ang = s_rz[k];
-                const int check = ((ang > 0 && ang < ang2) || (ang > ang1 && ang < 2 * kPiF));
-                sx += s_rx[k] * (float)check;
-                sy += s_ry[k] * (float)check;
-            }
+#pragma unroll
+        for (int k = 0; k < 109; ++k) {
+            const float ang = s_rz[k];
+            const uint64_t above = __builtin_amdgcn_ballot_w64(ang > ang1);
+            const uint64_t below = __builtin_amdgcn_ballot_w64(ang < ang2);
+            const uint64_t in = (above & below) | (wrapped & (above | below));
+            float tx, ty;
+            asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(tx) : "v"(s_rx[k]), "s"(in));
+            asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(ty) : "v"(s_ry[k]), "s"(in));
+            sx += tx;
+            sy += ty;
         }
         s_sx[tid] = sx;
         s_sy[tid] = sy;
