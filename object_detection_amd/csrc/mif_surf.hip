@@ -1068,7 +1068,9 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
                                                     const int* __restrict__ counts, float* __restrict__ desc,
                                                     NmsTable nms, const int* __restrict__ rowoff)
 {
+    constexpr int kGridN = 24;                           // sample positions per axis: k, l = -12 .. 11
     __shared__ float s_d[16][4][81];
+    __shared__ float s_g[4][kGridN * kGridN];            // per position: Haar x, Haar y, image column, image row
     __shared__ float s_len[16];
     {
         const size_t f = blockIdx.y;
@@ -1096,19 +1098,38 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
     const float thScale = scale[ip];
     const int hs = (int)(2 * mif_roundf(thScale));
     // The 81 samples of a sub-region form a 9 x 9 grid (k, l) rotated by the orientation: k moves a
-    // sample by thScale (co, si) pixels, l by thScale (-si, co). Consecutive threads take consecutive
-    // samples along the axis that changes the image COLUMN more, so that the lanes of a wave read along
-    // image rows rather than down a column (a cache line per lane). Which thread evaluates a sample does
-    // not enter the result: it lands in the sample's own slot s_d[.][.][tha].
+    // sample by thScale (co, si) pixels, l by thScale (-si, co). The grids of neighbouring sub-regions
+    // start 5 steps apart and so share 4 of their 9 rows and columns: the 16 x 81 samples lie on 24 x 24
+    // positions (k, l = -12 .. 11), and a sample's position and Haar responses depend on (k, l) alone
+    // (createDescriptors_kernel.cl:225-236), only its Gaussian weight on the sub-region. The responses are
+    // therefore evaluated once per position, 576 instead of 1296 times (eight reads of the integral
+    // image each, on different image rows from lane to lane: their number is what bounds the kernel), and
+    // every sample then takes its position's values from LDS.
+    // Consecutive threads take consecutive positions along the axis that changes the image COLUMN more,
+    // so that the lanes of a wave read along image rows rather than down a column (a cache line per lane).
 #ifdef MIF_SURF_NO_KFAST
     const bool k_fast = false;
 #else
     const bool k_fast = mif_fabsf(co) >= mif_fabsf(si);
 #endif
+    for (int item = tid; item < kGridN * kGridN; item += 256) {
+        const int a = item / kGridN, b = item - a * kGridN;
+        const int kk = k_fast ? b : a, ll = k_fast ? a : b;
+        const int k = kk - 12, l = ll - 12;
+        const int sample_x = (int)mif_roundf(x + ((float)(-l) * thScale * si + (float)k * thScale * co));
+        const int sample_y = (int)mif_roundf(y + ((float)l * thScale * co + (float)k * thScale * si));
+        float rx, ry;
+        haar_xy(img, width, height, sample_y, sample_x, hs, &rx, &ry);
+        const int slot = kk * kGridN + ll;
+        s_g[0][slot] = rx;
+        s_g[1][slot] = ry;
+        s_g[2][slot] = (float)sample_x;
+        s_g[3][slot] = (float)sample_y;
+    }
+    __syncthreads();
     for (int item = tid; item < 16 * 81; item += 256) {
         const int bIdx = item / 81;
-        const int t81 = item - bIdx * 81;
-        const int tha = k_fast ? (t81 % 9) * 9 + t81 / 9 : t81;
+        const int tha = item - bIdx * 81;
         const int j = c_tab_j[bIdx];
         const int i = c_tab_i[bIdx];
         const float ix = (float)(i + 5);
@@ -1117,11 +1138,9 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
         const float ys = mif_roundf(y + (jx * thScale * co + ix * thScale * si));
         const int k = i + (tha / 9);
         const int l = j + (tha % 9);
-        const int sample_x = (int)mif_roundf(x + ((float)(-l) * thScale * si + (float)k * thScale * co));
-        const int sample_y = (int)mif_roundf(y + ((float)l * thScale * co + (float)k * thScale * si));
-        const float gauss_s1 = gaussian(xs - (float)sample_x, ys - (float)sample_y, 2.5f * thScale);
-        float rx, ry;
-        haar_xy(img, width, height, sample_y, sample_x, hs, &rx, &ry);
+        const int slot = (k + 12) * kGridN + (l + 12);
+        const float gauss_s1 = gaussian(xs - s_g[2][slot], ys - s_g[3][slot], 2.5f * thScale);
+        const float rx = s_g[0][slot], ry = s_g[1][slot];
         const float rrx = gauss_s1 * (-rx * si + ry * co);
         const float rry = gauss_s1 * (rx * co + ry * si);
         s_d[bIdx][0][tha] = rrx;
