@@ -751,17 +751,23 @@ __device__ bool interpolate_extremum(const LayerView& t, const LayerView& m, con
 }
 
 // nonMaxSuppression_kernel.cl:306-364 for the six (bottom, middle, top)
-// triples in one launch: grid (words, max middle height, 6). The work items of
-// a launch span the middle layer; (c, r) are read as top-layer coordinates. A
-// wave stores its ballot of accepted positions as one bitmask word and adds
-// its count to the row total.
-__global__ __launch_bounds__(64) void k_nms_mark(LayerTable tab, NmsTable nms, const float* __restrict__ responses,
-                                                 const int* __restrict__ laps, float threshold,
-                                                 unsigned long long* __restrict__ mask, int* __restrict__ rowcnt,
-                                                 size_t pool)
+// triples in one launch: grid (words, ceil(rows / 4), frames) over the rows of all six middle layers laid
+// end to end (NmsDesc::row0), a wave per row and word of 64 columns. The work items of a launch of the
+// reference span the middle layer; (c, r) are read as top-layer coordinates. A wave stores its ballot of
+// accepted positions as one bitmask word and adds its count to the row total.
+__global__ __launch_bounds__(256) void k_nms_mark(LayerTable tab, NmsTable nms, const float* __restrict__ responses,
+                                                  const int* __restrict__ laps, float threshold,
+                                                  unsigned long long* __restrict__ mask, int* __restrict__ rowcnt,
+                                                  size_t pool)
 {
-    const int frame = blockIdx.z / kNms;
-    const NmsDesc d = nms.n[blockIdx.z - frame * kNms];
+    const int frame = blockIdx.z;
+    const int row = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= nms.rows) return;                         // uniform over the wave
+    int li = 0;
+    for (int i = 1; i < kNms; i++)
+        if (row >= nms.n[i].row0) li = i;
+    const NmsDesc d = nms.n[li];
     responses += (size_t)frame * pool;
     laps += (size_t)frame * pool;
     mask += (size_t)frame * nms.rows * nms.words;
@@ -769,18 +775,18 @@ __global__ __launch_bounds__(64) void k_nms_mark(LayerTable tab, NmsTable nms, c
     const LayerView b = view_of(tab, d.b, responses, laps);
     const LayerView m = view_of(tab, d.m, responses, laps);
     const LayerView t = view_of(tab, d.t, responses, laps);
-    const int r = blockIdx.y;
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (r >= m.h || blockIdx.x * 64 >= m.w) return;      // uniform over the wave
+    const int r = row - d.row0;
+    const int c = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= m.w) return;                  // uniform over the wave
     bool found = false;
     if (c < m.w && t.w > 0 && t.h > 0 && is_extremum(t, m, b, c, r, threshold)) {
         IptCore p;
         found = interpolate_extremum(t, m, b, r, c, &p);
     }
     const unsigned long long bits = __ballot(found);
-    if (threadIdx.x == 0) {
-        mask[(size_t)(d.row0 + r) * nms.words + blockIdx.x] = bits;
-        if (bits) atomicAdd(&rowcnt[d.row0 + r], __popcll(bits));
+    if (lane == 0) {
+        mask[(size_t)row * nms.words + blockIdx.x] = bits;
+        if (bits) atomicAdd(&rowcnt[row], __popcll(bits));
     }
 }
 
@@ -1423,7 +1429,8 @@ int surf_enqueue(mif_surf* s, const void* d_pixels, int nf)
     hipLaunchKernelGGL(k_hessian, dim3((lw + 15) / 16, (lh + 15) / 16, (kLayers - first) * nf), dim3(256), 0, st,
                        (const float*)s->integral, w, h, s->tab, s->responses, s->laplacians, s->pool, first);
     if (tm) MIF_HIP(hipEventRecord(s->ev_stage[2], st));
-    hipLaunchKernelGGL(k_nms_mark, dim3(s->nms.words, s->nms_max_h, kNms * nf), dim3(64), 0, st, s->tab, s->nms,
+    if (s->nms.rows > 0)
+        hipLaunchKernelGGL(k_nms_mark, dim3(s->nms.words, (s->nms.rows + 3) / 4, nf), dim3(256), 0, st, s->tab, s->nms,
                        (const float*)s->responses, (const int*)s->laplacians, kThres, s->mask, s->rowcnt, s->pool);
     hipLaunchKernelGGL(k_scan_counts, dim3(nf), dim3(1024), 0, st, (const int*)s->rowcnt, s->rowoff, s->nms.rows,
                        kMaxIpts, s->counts, (const int*)s->fault);
