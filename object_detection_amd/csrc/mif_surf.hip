@@ -966,10 +966,13 @@ __device__ __forceinline__ float gaussian(float x, float y, float sig)
 }
 
 // getOrientationStep1 + getOrientationStep2 (getOrientation_kernels.cl:161-316)
-// in one block of 128 threads per interest point: threads 0..108 evaluate the
-// 109 Haar samples, threads 0..41 sum the samples of their pi/3 window in
-// sample order, then the reference's max-magnitude tree picks the winner.
-__global__ __launch_bounds__(128) void k_orientation(const float* __restrict__ img, int w, int h,
+// in one block of ONE wave per interest point: the lanes evaluate the 109 Haar samples in two turns,
+// lanes 0..41 sum the samples of their pi/3 window in sample order, then the reference's max-magnitude
+// tree picks the winner. (With two waves per point the second had work in the first phase only; the
+// phases of a point follow one another, so what counts is how many points a compute unit has in flight:
+// 64 1080p frames 0.53 -> 0.40 ms.)
+constexpr int kOriThreads = 64;
+__global__ __launch_bounds__(kOriThreads) void k_orientation(const float* __restrict__ img, int w, int h,
                                                      const float2* __restrict__ pos, const float* __restrict__ scale,
                                                      const int* __restrict__ counts, float* __restrict__ orientation,
                                                      NmsTable nms, const int* __restrict__ rowoff)
@@ -997,8 +1000,8 @@ __global__ __launch_bounds__(128) void k_orientation(const float* __restrict__ i
     const int s = (int)mif_roundf(scale[ip]);
     const int r = (int)mif_roundf(pos[ip].y);
     const int c = (int)mif_roundf(pos[ip].x);
-    if (tid < 109) {
-        const int slot = c_orient_slot[tid];
+    for (int item = tid; item < 109; item += kOriThreads) {
+        const int slot = c_orient_slot[item];
         const int localId = c_orient_item[slot];
         const int i = localId / 13 - 6;
         const int j = localId % 13 - 6;
@@ -1448,7 +1451,7 @@ int surf_enqueue(mif_surf* s, const void* d_pixels, int nf)
     const int per_frame = per_frame_env > 0 ? 8 * ((per_frame_env + 7) / 8)
                                             : 8 * ((std::max(64, std::min(kMaxIpts / 2, 65536 / nf)) + 7) / 8);
     if (tm) MIF_HIP(hipEventRecord(s->ev_stage[3], st));
-    hipLaunchKernelGGL(k_orientation, dim3(per_frame, nf), dim3(128), 0, st, (const float*)s->integral, w, h,
+    hipLaunchKernelGGL(k_orientation, dim3(per_frame, nf), dim3(kOriThreads), 0, st, (const float*)s->integral, w, h,
                        (const float2*)s->pos, (const float*)s->scale, (const int*)s->counts, s->orient, s->nms,
                        (const int*)s->rowoff);
     if (tm) MIF_HIP(hipEventRecord(s->ev_stage[4], st));
