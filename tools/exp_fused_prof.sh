@@ -1,3 +1,7 @@
+#!/bin/bash
+# Kernel trace and two counter passes of the SURF batch with the one-launch integral image forced
+# (MIF_SURF_INTEGRAL=fused), printing the lines of k_integral_fused:
+#   gpurun -- 'bash tools/exp_fused_prof.sh'      (writes under gpurun_out/fused_*)
 export TMPDIR=/tmp; R=$PWD; cd /tmp
 export MIF_SURF_INTEGRAL=fused
 SURF="python3 $R/tools/bench_surf.py --skip-single --batch 64 --steps 5"
