@@ -260,7 +260,10 @@ int mif_surf_run(mif_surf* s, const uint8_t* pixels, mif_ipoint* points, int cap
 /* Device-resident form: d_pixels lives in HBM, work is enqueued on the handle's
  * stream, results stay on the device: pos float2[8000], scale float[8000],
  * laplacian int32[8000], orientation float[8000], descriptors float[8000][64],
- * counts int32[2] = {points, raw}. Any out pointer may be NULL. */
+ * counts int32[2] = {points, raw}. Any out pointer may be NULL.
+ * Batches of 192 bands of 64 image rows and more build their integral images in one launch whose bands
+ * wait for each other through memory; the wait is bounded, and a batch in which a band gave up has
+ * counts = {0, -2} for every frame (mif_surf_copy_points and mif_surf_run then return MIF_ERR_HIP). */
 int mif_surf_enqueue(mif_surf* s, const void* d_pixels);
 /* nframes (<= batch) frames back to back in HBM; frame f's results start at row f * 8000 of the point
  * arrays of mif_surf_device_results and at counts + 2 f. */
