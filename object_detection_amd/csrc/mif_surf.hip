@@ -626,24 +626,31 @@ __global__ __launch_bounds__(256) void k_hessian_staged(const float* __restrict_
     const int wx0 = (int)blockIdx.x * kHessTileOut * kSampleStep - kHessReachLo;
     const int wy0 = (int)blockIdx.y * kHessTileOut * kSampleStep - kHessReachLo;
     {
-        // all of a thread's loads are issued before its first LDS store (clamped addresses, zeros selected
-        // afterwards), so that their latencies overlap
-        constexpr int kTurns = (kHessWin * kHessWin + 255) / 256;
-        float v[kTurns];
+        // A thread owns one column of every second row of the window (columns 104 .. 127 of the thread
+        // grid idle): the column's clamped address and its inside test are formed once, a turn costs the
+        // row's clamp, one load and one store. The loads of sixteen turns are issued before their LDS stores
+        // (clamped addresses, zeros selected afterwards), so that their latencies overlap.
+        const int lx = tid & 127, ty = tid >> 7;
+        const int gx = wx0 + lx;
+        const bool inx = gx >= 0 && gx < width;
+        const float* col = img + min(max(gx, 0), width - 1);
+        constexpr int kTurns = (kHessWin + 1) / 2, kGroup = 13;
+        static_assert(kTurns % kGroup == 0, "turns come in whole groups");
+        if (lx < kHessWin) {
+            for (int g0 = 0; g0 < kTurns; g0 += kGroup) {
+                float v[kGroup];
 #pragma unroll
-        for (int it = 0; it < kTurns; it++) {
-            const int i = min(tid + 256 * it, kHessWin * kHessWin - 1);
-            const int ly = i / kHessWin, lx = i - ly * kHessWin;
-            const int gy = min(max(wy0 + ly, 0), height - 1), gx = min(max(wx0 + lx, 0), width - 1);
-            v[it] = img[gy * width + gx];
-        }
+                for (int it = 0; it < kGroup; it++) {
+                    const int gy = wy0 + ty + 2 * (g0 + it);
+                    v[it] = col[min(max(gy, 0), height - 1) * width];
+                }
 #pragma unroll
-        for (int it = 0; it < kTurns; it++) {
-            const int i = tid + 256 * it;
-            const int ly = i / kHessWin, lx = i - ly * kHessWin;
-            const int gy = wy0 + ly, gx = wx0 + lx;
-            const bool inside = gy >= 0 && gx >= 0 && gy < height && gx < width;
-            if (i < kHessWin * kHessWin) s_win[ly * kHessPitch + lx] = inside ? v[it] : 0.0f;
+                for (int it = 0; it < kGroup; it++) {
+                    const int ly = ty + 2 * (g0 + it);
+                    const int gy = wy0 + ly;
+                    s_win[ly * kHessPitch + lx] = (inx && gy >= 0 && gy < height) ? v[it] : 0.0f;
+                }
+            }
         }
     }
     __syncthreads();
