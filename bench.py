@@ -47,6 +47,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
+
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """One line on stderr per finished part of the run (rank 0): stdout carries the JSON line only."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %6.1f s] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak
 MFMA_F32_PEAK_TFLOPS = 157.3     # dense fp32 matrix peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 matrix peak
@@ -786,6 +795,7 @@ def surf_batch_leg(args, oda, torch, device, local_rank, frames):
     mif_surf_enqueue_batch; frames/s, the integral image's achieved bandwidth against 7 B/px (3 read, 4 written), frame 1
     compared with the CPU checker, and the checker's own rate beside it."""
     import oracle_lib as orc
+    progress("SURF batch leg starts")
     B, w, h = args.config_batch, 1920, 1080
     # `frames`: two rendered 1080p BGR frames, repeated to fill the batch
     px = torch.from_numpy(frames).to(device).repeat((B + 1) // 2, 1, 1, 1)[:B].contiguous()
@@ -856,6 +866,7 @@ def sift_4k_leg(args, oda, torch, device, local_rank, frames_16):
     extraction only; frames/s, the scale-space launches against the HBM peak, frame 1 compared with the
     CPU checker and the checker's own rate beside it."""
     import oracle_lib as orc
+    progress("4K batch leg starts")
     B, w, h = args.config_batch, 3840, 2160
     reps = (B + len(frames_16) - 1) // len(frames_16)
     px = torch.from_numpy(frames_16).to(device).repeat(reps, 1, 1)[:B].contiguous()
@@ -1125,6 +1136,7 @@ def main():
     summ = pipe.summ[pipe.last()].cpu().numpy()
     counts = pipe.h[pipe.last()].read_counts(args.batch - 1)
 
+    progress("resident-frames steps timed")
     # the same frames through the CPU checker: frame 1 of the last batch must agree with it
     # (frames 1, batch / 2 and batch - 1 of the headline run; the later legs re-check frame 1)
     verified, verify_detail, want, verified_frames = None, None, None, None
@@ -1138,6 +1150,7 @@ def main():
             verified_frames[f] = ok_f
             verified = bool(verified and ok_f)
 
+    progress("headline batch checked against the CPU checker")
     # PCIe-inclusive rate: the same step fed from pinned host memory, summaries back on the host
     host_leg = None
     if not args.no_host_leg and not args.host_frames and not args.no_match:
@@ -1195,6 +1208,7 @@ def main():
             verified = bool(verified and ok_f)
         del fd
 
+    progress("host-to-host legs done")
     # informational: the same resident-frames step with the two handles free-running on a stream each.
     # Not `value`: the kernels of two batches then overlap in time, so no per-kernel duration (the roofline
     # block, a rocprofv3 summary) says what a kernel achieves by itself any more.
@@ -1290,6 +1304,7 @@ def main():
     else:
         out = None
 
+    progress("frame pipeline legs done")
     # The frame pipeline's memory is released before the other blocks. The pinned buffers go first: torch's
     # host allocator records an event on every stream that used them when they are freed, and the handles'
     # stream is gone once the pipeline is.
@@ -1313,6 +1328,7 @@ def main():
         if rank == 0:
             out["matcher"] = blk
 
+    progress("matcher block done")
     # The other configurations of BASELINE.json (one GPU; the pair legs ran as child processes above)
     configs_ok = True
     if rank == 0 and world == 1 and not args.no_configs:
@@ -1324,11 +1340,13 @@ def main():
                "C5_match_1Mx1M": "the `matcher` block of this line"}
         configs_ok = all(v.get("verified", False) for v in cfg.values() if isinstance(v, dict))
         out["configs"] = cfg
+        progress("configuration legs done")
 
     rc = 0
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_seconds, match=not args.no_match)
+            progress("CPU baseline done")
         print(json.dumps(out), flush=True)
         if verified is False or not match_ok or not configs_ok:
             print("bench.py: results differ from the CPU checker or between the two matcher forms, or the "

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(64) void k_scan_cols_serial(float* __restrict__ img
 // band waits for nobody: every wait ends. The wait is bounded all the same; a band that gives up raises
 // `fault` (k_scan_counts then reports the frame as failed) and goes on with zeros.
 constexpr int kFuPitch = 65;
-constexpr int kFuSpin = 1 << 21;
+constexpr int kFuSpin = 1 << 19;             // polls before a band gives up (a fraction of a second)
 constexpr int kFusedMinBands = 192;     // bands of a batch from which the one-launch form is used (measured:
                                         // 1080p, 8 frames = 136 bands 3 % slower than two launches, 16 frames = 272 bands 3.5 % faster)
 
@@ -409,6 +409,7 @@ __global__ __launch_bounds__(256) void k_integral_fused(const uint8_t* __restric
             step_barrier();
         }
     } else {
+        bool gave_up = false;
         for (int s = 0; s < ncb + 2; s++) {
             if (s >= 2) {
                 const float* t = s_t[(s - 2) % 3];
@@ -427,9 +428,9 @@ __global__ __launch_bounds__(256) void k_integral_fused(const uint8_t* __restric
                 }
                 float prev = 0.0f;
                 if (chained) {
-                    int tries = 0;
+                    int tries = gave_up ? kFuSpin - 1 : 0;     // a band that gave up once does not wait again
                     while ((unsigned int)(v >> 32) != epoch) {
-                        if (++tries >= kFuSpin) { atomicExch(fault, 1); v = 0ull; break; }
+                        if (++tries >= kFuSpin) { atomicExch(fault, 1); gave_up = true; v = 0ull; break; }
                         __builtin_amdgcn_s_sleep(1);
                         v = __hip_atomic_load(&carry_in[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
