@@ -846,6 +846,7 @@ def surf_batch_leg(args, oda, torch, device, local_rank, frames):
         "value": B / dt, "unit": "frames/s", "ms_per_step": dt * 1e3, "steps": args.config_steps,
         "points_frame1": int(n),
         "stage_ms_per_batch": {k: float(v) for k, v in zip(ex.STAGES, stage)},
+        "integral_fallbacks": ex.integral_fallbacks(),     # batches the launch-per-pass form had to redo: 0
         "roofline": {"bound": "hbm", "kernel": "integral image (k_integral_fused: row scan and column scan in one "
                                                "launch; the stage's time includes clearing the response pools)",
                      "achieved": integ, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": integ / HBM_PEAK_GBS,

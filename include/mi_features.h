@@ -262,8 +262,8 @@ int mif_surf_run(mif_surf* s, const uint8_t* pixels, mif_ipoint* points, int cap
  * laplacian int32[8000], orientation float[8000], descriptors float[8000][64],
  * counts int32[2] = {points, raw}. Any out pointer may be NULL.
  * Batches of 192 bands of 64 image rows and more build their integral images in one launch whose bands
- * wait for each other through memory; the wait is bounded, and a batch in which a band gave up has
- * counts = {0, -2} for every frame (mif_surf_copy_points and mif_surf_run then return MIF_ERR_HIP). */
+ * wait for each other through memory; the wait is bounded, and a batch in which a band gave up is built
+ * again by the launch-per-pass kernels enqueued behind it (same results, later). */
 int mif_surf_enqueue(mif_surf* s, const void* d_pixels);
 /* nframes (<= batch) frames back to back in HBM; frame f's results start at row f * 8000 of the point
  * arrays of mif_surf_device_results and at counts + 2 f. */
@@ -272,6 +272,9 @@ int mif_surf_enqueue_batch(mif_surf* s, const void* d_pixels, int nframes);
  * out as for mif_surf_run. */
 int mif_surf_copy_points(mif_surf* s, int frame, mif_ipoint* points, int capacity, int* count, int* raw_count);
 int mif_surf_sync(mif_surf* s);
+/* Waits for the stream; *count = batches of this handle whose integral images had to be built again (see
+ * mif_surf_enqueue). No counterpart in the reference: a diagnostic, expected to stay 0. */
+int mif_surf_integral_fallbacks(mif_surf* s, int* count);
 void* mif_surf_stream(mif_surf* s);
 int mif_surf_device_results(mif_surf* s, void** d_pos, void** d_scale, void** d_laplacian, void** d_orientation,
                             void** d_descriptors, void** d_counts);

@@ -56,6 +56,7 @@ SYMBOLS = [
     ("mif_surf_create", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("mif_surf_create_batched", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     ("mif_surf_batch", C.c_int, [_P]),
+    ("mif_surf_integral_fallbacks", C.c_int, [_P, C.POINTER(C.c_int)]),
     ("mif_surf_enqueue_batch", C.c_int, [_P, _P, C.c_int]),
     ("mif_surf_copy_points", C.c_int, [_P, C.c_int, _P, C.c_int, _PI, _PI]),
     ("mif_surf_copy_integral_frame", C.c_int, [_P, C.c_int, _P]),

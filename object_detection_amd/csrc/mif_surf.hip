@@ -131,9 +131,12 @@ __device__ __forceinline__ float wave_scan64(float v, int lane)
 // conversion): one wave per image row marches along it 64 pixels at a time.
 // All kernels below take the frame of a batch from a grid dimension and address per-frame data at
 // frame * stride.
+// `only_if` (all three scan kernels; may be NULL): the launch does its work only when *only_if is not
+// zero -- the launches that stand behind k_integral_fused and redo a batch whose bands gave up waiting.
 __global__ __launch_bounds__(256) void k_scan_rows(const uint8_t* __restrict__ px, float* __restrict__ out, int w,
-                                                   int h, int channels)
+                                                   int h, int channels, const int* __restrict__ only_if)
 {
+    if (only_if && *only_if == 0) return;            // uniform over the grid
     constexpr int G = 8;                             // 64-pixel chunks whose loads are issued together
     const int lane = threadIdx.x & 63;
     const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -182,8 +185,10 @@ constexpr int kColMaxBlocks = 128;      // row blocks per strip the totals table
 
 // (Workgroups of 9 waves, so that the 17 row blocks of 1080 rows take two equally full rounds instead of
 // 16 + 1, were measured: 415 instead of 368 us per 64 frames.)
-__global__ __launch_bounds__(64 * kColWaves) void k_scan_cols(float* __restrict__ img, int w, int h)
+__global__ __launch_bounds__(64 * kColWaves) void k_scan_cols(float* __restrict__ img, int w, int h,
+                                                              const int* __restrict__ only_if)
 {
+    if (only_if && *only_if == 0) return;
     __shared__ float s_tot[kColMaxBlocks * 64];      // [row blocks][64]
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -219,8 +224,10 @@ __global__ __launch_bounds__(64 * kColWaves) void k_scan_cols(float* __restrict_
 
 // The same pass with one lane per column walking all row blocks one after the other: for images taller
 // than the tiled kernel's totals table.
-__global__ __launch_bounds__(64) void k_scan_cols_serial(float* __restrict__ img, int w, int h)
+__global__ __launch_bounds__(64) void k_scan_cols_serial(float* __restrict__ img, int w, int h,
+                                                         const int* __restrict__ only_if)
 {
+    if (only_if && *only_if == 0) return;
     const int x = blockIdx.x * 64 + threadIdx.x;
     if (x >= w) return;
     img += (size_t)blockIdx.y * w * h;
@@ -264,7 +271,8 @@ __global__ __launch_bounds__(64) void k_scan_cols_serial(float* __restrict__ img
 // bands of a frame run one tile behind each other. Bands take their number from a ticket counter, frame
 // major and top to bottom, so the band a workgroup waits for has always started before it, and the top
 // band waits for nobody: every wait ends. The wait is bounded all the same; a band that gives up raises
-// `fault` (k_scan_counts then reports the frame as failed) and goes on with zeros.
+// `fault`, goes on with zeros and waits no more, and the launch-per-pass kernels that stand behind this
+// launch (they leave at once otherwise) then build the batch's integral images again.
 constexpr int kFuPitch = 65;
 constexpr int kFuSpin = 1 << 19;             // polls before a band gives up (a fraction of a second)
 constexpr int kFusedMinBands = 192;     // bands of a batch from which the one-launch form is used (measured:
@@ -274,8 +282,8 @@ template <int CH, bool A4>
 __global__ __launch_bounds__(256) void k_integral_fused(const uint8_t* __restrict__ px, float* __restrict__ out, int w,
                                                         int h, int nbands, int nitems,
                                                         unsigned long long* __restrict__ carry, int wpad,
-                                                        unsigned int epoch, unsigned int* __restrict__ ticket,
-                                                        int* __restrict__ fault)
+                                                        unsigned int epoch, unsigned int epoch_wait,
+                                                        unsigned int* __restrict__ ticket, int* __restrict__ fault)
 {
     __shared__ float s_t[3][64 * kFuPitch];
     __shared__ int s_item;
@@ -429,7 +437,7 @@ __global__ __launch_bounds__(256) void k_integral_fused(const uint8_t* __restric
                 float prev = 0.0f;
                 if (chained) {
                     int tries = gave_up ? kFuSpin - 1 : 0;     // a band that gave up once does not wait again
-                    while ((unsigned int)(v >> 32) != epoch) {
+                    while ((unsigned int)(v >> 32) != epoch_wait) {
                         if (++tries >= kFuSpin) { atomicExch(fault, 1); gave_up = true; v = 0ull; break; }
                         __builtin_amdgcn_s_sleep(1);
                         v = __hip_atomic_load(&carry_in[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -458,6 +466,16 @@ __global__ __launch_bounds__(256) void k_integral_fused(const uint8_t* __restric
             }
             step_barrier();
         }
+    }
+}
+
+// Behind the launches that redo a batch after k_integral_fused gave up: counts the event and clears the
+// mark, so that the stages downstream see a good batch.
+__global__ void k_fault_handled(int* __restrict__ fault, int* __restrict__ fallbacks)
+{
+    if (*fault != 0) {
+        *fallbacks += 1;
+        *fault = 0;
     }
 }
 
@@ -1301,6 +1319,7 @@ struct mif_surf {
     int* fault = nullptr;                // k_integral_fused: a band gave up waiting
     unsigned long long* carry = nullptr; // k_integral_fused: [batch][bands][columns padded to 64] {total, launch}
     unsigned int epoch = 0;              // launch number of the last fused launch
+    int* fallbacks = nullptr;            // batches that the launch-per-pass form had to redo (device counter)
     mif_ipoint* packed = nullptr;        // the points as mif_ipoint records, for a single download
     int* rowoff = nullptr;
     int* counts = nullptr;               // {points (cut at 8000), raw total}
@@ -1317,7 +1336,7 @@ namespace {
 void surf_free(mif_surf* s)
 {
     (void)hipFree(s->d_pixels); (void)hipFree(s->integral); (void)hipFree(s->cleared); (void)hipFree(s->rowoff);
-    (void)hipFree(s->packed); (void)hipFree(s->carry);
+    (void)hipFree(s->packed); (void)hipFree(s->carry); (void)hipFree(s->fallbacks);
     (void)hipFree(s->counts); (void)hipFree(s->pos); (void)hipFree(s->scale); (void)hipFree(s->lap);
     (void)hipFree(s->orient); (void)hipFree(s->desc);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
@@ -1382,6 +1401,8 @@ int surf_create_impl(mif_surf* s)
         const size_t carry_bytes = B * (size_t)((s->H + 63) / 64) * (size_t)((s->W + 63) / 64 * 64) * sizeof(unsigned long long);
         MIF_HIP(hipMalloc(&s->carry, carry_bytes));
         MIF_HIP(hipMemset(s->carry, 0, carry_bytes));
+        MIF_HIP(hipMalloc(&s->fallbacks, sizeof(int)));
+        MIF_HIP(hipMemset(s->fallbacks, 0, sizeof(int)));
     }
     MIF_HIP(hipMalloc(&s->packed, B * kMaxIpts * sizeof(mif_ipoint)));
     MIF_HIP(hipMalloc(&s->rowoff, B * (size_t)std::max(rows, 1) * sizeof(int)));
@@ -1436,19 +1457,29 @@ int surf_enqueue(mif_surf* s, const void* d_pixels, int nf)
         }
         // (four pixels per load where every row of every frame starts on a 4-byte boundary)
         const bool a4 = w % 4 == 0 && (uintptr_t)d_pixels % 4 == 0;
+        // (MIF_SURF_INTEGRAL_TEST_FAULT: the bands wait for a launch number nobody writes, give up, and the
+        // launches behind redo the batch; for the test of that path)
+        const char* test_fault = getenv("MIF_SURF_INTEGRAL_TEST_FAULT");
+        const unsigned int epoch_wait = (test_fault && test_fault[0] == '1') ? s->epoch + 0x40000000u : s->epoch;
 #define MIF_LAUNCH_FUSED(CH, A4)                                                                                          \
     hipLaunchKernelGGL((k_integral_fused<CH, A4>), dim3(nbands * nf), dim3(256), 0, st, (const uint8_t*)d_pixels,          \
-                       s->integral, w, h, nbands, nbands * nf, s->carry, (w + 63) / 64 * 64, s->epoch, s->ticket, s->fault)
+                       s->integral, w, h, nbands, nbands * nf, s->carry, (w + 63) / 64 * 64, s->epoch, epoch_wait,         \
+                       s->ticket, s->fault)
         if (s->C == 3) { if (a4) MIF_LAUNCH_FUSED(3, true); else MIF_LAUNCH_FUSED(3, false); }
         else { if (a4) MIF_LAUNCH_FUSED(1, true); else MIF_LAUNCH_FUSED(1, false); }
 #undef MIF_LAUNCH_FUSED
-    } else {
+    }
+    // a launch per pass: the form of single frames and small batches, and behind the one-launch form the
+    // stand-in that runs only for a batch whose bands gave up waiting for each other
+    {
+        const int* only_if = fused ? s->fault : nullptr;
         hipLaunchKernelGGL(k_scan_rows, dim3((h + 3) / 4, nf), dim3(256), 0, st, (const uint8_t*)d_pixels, s->integral, w, h,
-                           s->C);
+                           s->C, only_if);
         if ((h + 63) / 64 <= kColMaxBlocks)
-            hipLaunchKernelGGL(k_scan_cols, dim3((w + 63) / 64, nf), dim3(64 * kColWaves), 0, st, s->integral, w, h);
+            hipLaunchKernelGGL(k_scan_cols, dim3((w + 63) / 64, nf), dim3(64 * kColWaves), 0, st, s->integral, w, h, only_if);
         else
-            hipLaunchKernelGGL(k_scan_cols_serial, dim3((w + 63) / 64, nf), dim3(64), 0, st, s->integral, w, h);
+            hipLaunchKernelGGL(k_scan_cols_serial, dim3((w + 63) / 64, nf), dim3(64), 0, st, s->integral, w, h, only_if);
+        if (fused) hipLaunchKernelGGL(k_fault_handled, dim3(1), dim3(1), 0, st, s->fault, s->fallbacks);
     }
     if (tm) MIF_HIP(hipEventRecord(s->ev_stage[1], st));
     // the first octave's four layers from a window staged in LDS where they share one output grid (they do
@@ -1643,6 +1674,15 @@ int mif_surf_run(mif_surf* s, const uint8_t* pixels, mif_ipoint* points, int cap
     if (n == 0) return MIF_OK;
     MIF_HIP(hipMemcpy(points, s->packed, (size_t)n * sizeof(mif_ipoint), hipMemcpyDeviceToHost));
     *count = n;
+    return MIF_OK;
+}
+
+int mif_surf_integral_fallbacks(mif_surf* s, int* count)
+{
+    if (!s || !count) return MIF_ERR_INVALID_ARGUMENT;
+    mif::DeviceGuard guard(s->device);
+    MIF_HIP(hipStreamSynchronize(s->stream));
+    MIF_HIP(hipMemcpy(count, s->fallbacks, sizeof(int), hipMemcpyDeviceToHost));
     return MIF_OK;
 }
 

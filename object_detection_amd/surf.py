@@ -71,6 +71,12 @@ class SurfExtractor:
 
     STAGES = ("integral_image", "hessian_det", "non_max_supression", "getOrientation", "createDescriptors")
 
+    def integral_fallbacks(self):
+        """Batches whose integral images the launch-per-pass form had to build again (expected: 0)."""
+        n = C.c_int(0)
+        _lib.check(self._lib.mif_surf_integral_fallbacks(self._h, C.byref(n)))
+        return n.value
+
     def set_timing(self, enable=True):
         _lib.check(self._lib.mif_surf_set_timing(self._h, 1 if enable else 0))
 

@@ -155,6 +155,33 @@ def test_surf_batch_with_both_passes_of_the_integral_image_in_one_launch(w, h, c
     ex.close()
 
 
+def test_surf_batch_whose_bands_give_up_waiting_is_built_again(monkeypatch):
+    """MIF_SURF_INTEGRAL_TEST_FAULT=1 makes the bands of the one-launch integral image wait for a launch
+    number nobody writes: every band gives up (a bounded wait), and the launch-per-pass kernels enqueued
+    behind build the batch again. Results equal the checker's, the handle counts the event, and the next
+    batch (switch off) goes through the one-launch form untroubled."""
+    import torch
+    w, h, B = 200, 130, 64
+    frames = np.stack([blob_image(w, h, seed=500 + i, channels=3) for i in range(B)])
+    px = torch.from_numpy(frames).to(torch.device("cuda:0"))
+    ex = oda.SurfExtractor(w, h, 3, batch=B)
+    S = orc.SurfOracle(w, h)
+    assert ex.integral_fallbacks() == 0
+    for forced, expect in ((True, 1), (False, 1)):
+        if forced:
+            monkeypatch.setenv("MIF_SURF_INTEGRAL_TEST_FAULT", "1")
+        else:
+            monkeypatch.delenv("MIF_SURF_INTEGRAL_TEST_FAULT")
+        ex.enqueue_batch(px.data_ptr(), B)
+        for f in (0, 31, 63):
+            n = S.run(frames[f])
+            assert np.array_equal(ex.integral(f).view(np.uint32), S.integral().view(np.uint32)), (forced, f)
+            pts, raw = ex.copy_points(f)
+            assert len(pts) == n and raw == S.raw_count(), (forced, f)
+        assert ex.integral_fallbacks() == expect
+    ex.close()
+
+
 def test_surf_tall_image_column_scan():
     """More rows than the tiled column scan's table of block totals holds (8192): the one-lane-per-column
     form takes over; the integral image still equals the checker's."""
