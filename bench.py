@@ -116,6 +116,10 @@ def parse_args(argv=None):
     ap.add_argument("--match-steps", type=int, default=2, help="timed passes per form of the matcher block")
     ap.add_argument("--match-timeout", type=int, default=300,
                     help="seconds after which a multi-rank matcher block is given up (the line is printed without it)")
+    ap.add_argument("--deadline", type=int, default=540,
+                    help="seconds after the start at which rank 0 prints the line as far as it has got (the frame "
+                         "pipeline's figures are complete by then, later blocks may be missing; exit code 4) instead "
+                         "of running on; 0 = no deadline")
     ap.add_argument("--no-verify", action="store_true", help="skip the comparison with the CPU checker")
     ap.add_argument("--native-pipeline", action="store_true",
                     help="drive the same schedule through the library's own pipeline object (mif_video_*) "
@@ -1305,6 +1309,23 @@ def main():
     else:
         out = None
 
+    # From here on the headline figures exist. A block further down that stalls must not cost the run its
+    # line: at the deadline rank 0 prints what it has and leaves.
+    watchdog = None
+    if rank == 0 and args.deadline > 0:
+        import threading
+
+        def give_up():
+            out["truncated"] = ("the run reached its deadline of %d s: blocks after the frame pipeline are missing "
+                                "or partial" % args.deadline)
+            print(json.dumps(out), flush=True)
+            print("bench.py: deadline reached, line printed as far as the run got", file=sys.stderr, flush=True)
+            os._exit(4)
+
+        watchdog = threading.Timer(max(1.0, args.deadline - (time.perf_counter() - _T0)), give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
     progress("frame pipeline legs done")
     # The frame pipeline's memory is released before the other blocks. The pinned buffers go first: torch's
     # host allocator records an event on every stream that used them when they are freed, and the handles'
@@ -1348,6 +1369,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames_np, args.cpu_seconds, match=not args.no_match)
             progress("CPU baseline done")
+        if watchdog is not None:
+            watchdog.cancel()
         print(json.dumps(out), flush=True)
         if verified is False or not match_ok or not configs_ok:
             print("bench.py: results differ from the CPU checker or between the two matcher forms, or the "
