@@ -1116,6 +1116,9 @@ __global__ __launch_bounds__(kOriThreads) void k_orientation(const float* __rest
 
 // -------------------------------------------------------------- descriptor
 
+constexpr int kIpointWords = (int)(sizeof(mif_ipoint) / 4);
+static_assert(kIpointWords == 70, "mif_ipoint is 70 words");
+
 // createDescriptors (createDescriptors_kernel.cl:160-275) fused with
 // normalizeDescriptors (normalizeDescriptors_kernel.cl:54-111): one block of
 // 256 threads per interest point evaluates the 16 x 81 rotated Haar samples,
@@ -1126,7 +1129,8 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
                                                     const float2* __restrict__ pos, const float* __restrict__ scale,
                                                     const float* __restrict__ orientation,
                                                     const int* __restrict__ counts, float* __restrict__ desc,
-                                                    NmsTable nms, const int* __restrict__ rowoff)
+                                                    NmsTable nms, const int* __restrict__ rowoff,
+                                                    const int* __restrict__ lap, uint32_t* __restrict__ packed)
 {
     constexpr int kGridN = 24;                           // sample positions per axis: k, l = -12 .. 11
     __shared__ float s_d[16][4][81];
@@ -1141,6 +1145,8 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
         desc += f * kMaxIpts * 64;
         counts += f * 2;
         rowoff += f * nms.rows;
+        lap += f * kMaxIpts;
+        packed += f * kMaxIpts * kIpointWords;
     }
     const int tid = threadIdx.x;
     const int n_ipts = counts[0];
@@ -1247,9 +1253,20 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
         if (tid < i) s_len[tid] += s_len[tid + i];
         __syncthreads();
     }
+    // the point's record (mif_ipoint: x, y, scale, orientation, laplacian, 0, descriptor[64]; the layout of
+    // ccl_surf::Ipoint, ccl_surf.h:11-21) is written here as well, so that a host caller fetches the points
+    // of a frame with one copy
     if (tid < 64) {
         const float lengthOfDescriptor = 1.0f / __builtin_sqrtf(s_len[0]);
-        desc[(size_t)ip * 64 + tid] = mine * lengthOfDescriptor;
+        const float d = mine * lengthOfDescriptor;
+        desc[(size_t)ip * 64 + tid] = d;
+        packed[(size_t)ip * kIpointWords + 6 + tid] = __float_as_uint(d);
+    } else if (tid < 64 + 6) {
+        const int k = tid - 64;
+        const uint32_t v = k == 0 ? __float_as_uint(pos[ip].x) : k == 1 ? __float_as_uint(pos[ip].y)
+                         : k == 2 ? __float_as_uint(scale[ip]) : k == 3 ? __float_as_uint(orientation[ip])
+                         : k == 4 ? (uint32_t)lap[ip] : 0u;
+        packed[(size_t)ip * kIpointWords + k] = v;
     }
     __syncthreads();                                 // the shared arrays are reused by the next point
     }
@@ -1258,41 +1275,6 @@ __global__ __launch_bounds__(256) void k_descriptor(const float* __restrict__ im
 
 } // namespace
 
-namespace {
-
-// The interest points as mif_ipoint records (70 words: x, y, scale, orientation, laplacian, 0,
-// descriptor[64]; the layout of ccl_surf::Ipoint, ccl_surf.h:11-21), so that a host caller fetches
-// them with one copy.
-__global__ void k_pack_points(const float2* __restrict__ pos, const float* __restrict__ scale,
-                              const float* __restrict__ orient, const int* __restrict__ lap,
-                              const float* __restrict__ desc, const int* __restrict__ counts,
-                              uint32_t* __restrict__ out)
-{
-    constexpr int kWords = (int)(sizeof(mif_ipoint) / 4);
-    static_assert(kWords == 70, "mif_ipoint is 70 words");
-    {
-        const size_t f = blockIdx.y;
-        pos += f * kMaxIpts; scale += f * kMaxIpts; orient += f * kMaxIpts; lap += f * kMaxIpts;
-        desc += f * kMaxIpts * 64;
-        counts += f * 2;
-        out += f * kMaxIpts * kWords;
-    }
-    const int total = counts[0] * kWords;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int p = i / kWords, k = i - p * kWords;
-        uint32_t v;
-        if (k >= 6) v = __float_as_uint(desc[(size_t)p * 64 + (k - 6)]);
-        else if (k == 0) v = __float_as_uint(pos[p].x);
-        else if (k == 1) v = __float_as_uint(pos[p].y);
-        else if (k == 2) v = __float_as_uint(scale[p]);
-        else if (k == 3) v = __float_as_uint(orient[p]);
-        else if (k == 4) v = (uint32_t)lap[p];
-        else v = 0u;
-        out[i] = v;
-    }
-}
-
-} // namespace
 
 struct mif_surf {
     int device = 0, W = 0, H = 0, C = 1, batch = 1;
@@ -1522,10 +1504,7 @@ int surf_enqueue(mif_surf* s, const void* d_pixels, int nf)
     if (tm) MIF_HIP(hipEventRecord(s->ev_stage[4], st));
     hipLaunchKernelGGL(k_descriptor, dim3(per_frame, nf), dim3(256), 0, st, (const float*)s->integral, w, h,
                        (const float2*)s->pos, (const float*)s->scale, (const float*)s->orient, (const int*)s->counts,
-                       s->desc, s->nms, (const int*)s->rowoff);
-    hipLaunchKernelGGL(k_pack_points, dim3(64, nf), dim3(256), 0, st, (const float2*)s->pos, (const float*)s->scale,
-                       (const float*)s->orient, (const int*)s->lap, (const float*)s->desc, (const int*)s->counts,
-                       reinterpret_cast<uint32_t*>(s->packed));
+                       s->desc, s->nms, (const int*)s->rowoff, (const int*)s->lap, reinterpret_cast<uint32_t*>(s->packed));
     MIF_HIP(hipGetLastError());
     if (tm) {
         MIF_HIP(hipEventRecord(s->ev_stage[5], st));
